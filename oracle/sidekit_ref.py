@@ -1,0 +1,412 @@
+"""CPU oracle for the GMM-UBM / i-vector statistics hot path (TEST INFRASTRUCTURE ONLY).
+
+This is a plain NumPy/SciPy float64 restatement of what the reference (SIDEKIT 1.3.2 as
+vendored in Anwarvic/Speaker-Recognition) computes on the hot path.  It is NOT the product:
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it; the shipped package (``speaker-recognition_amd/``) never does and fails loudly when the
+HIP library is missing.
+
+Parity status: PINNED.  Every function below is checked in ``tests/test_oracle_golden.py``
+against golden vectors produced by importing the real reference in the build container
+(``tools/gen_golden.py``; fixtures in ``tests/golden/*.npz``).  The reference has no tests or
+golden vectors of its own, so those generated fixtures are the pin.
+
+Each function cites the reference file:line it follows (paths relative to the reference
+root).  Quirks of the reference are reproduced on purpose (second moment used as covariance
+in the 1-Gaussian init, `<=`/`>=` in the variance control, float32 in-place whitening in the
+TV E-step, upper Cholesky factor in minimum divergence ...).
+"""
+import math
+
+import numpy as np
+import scipy.linalg
+
+F64 = np.float64
+
+
+# ----------------------------------------------------------------------------------------
+# GMM container
+# ----------------------------------------------------------------------------------------
+class GMM(object):
+    """Diagonal-covariance GMM parameters (sidekit/mixture.py:181-197)."""
+
+    __slots__ = ("w", "mu", "invcov", "cov_var_ctl", "cst", "det", "A")
+
+    def __init__(self, w, mu, invcov, cov_var_ctl=None):
+        self.w = np.array(w, dtype=F64)
+        self.mu = np.array(mu, dtype=F64)
+        self.invcov = np.array(invcov, dtype=F64)
+        self.cov_var_ctl = (1.0 / self.invcov) if cov_var_ctl is None else np.array(cov_var_ctl, dtype=F64)
+        self.cst = None
+        self.det = None
+        self.A = None
+        self.refresh()
+
+    def copy(self):
+        g = GMM.__new__(GMM)
+        for k in self.__slots__:
+            v = getattr(self, k)
+            setattr(g, k, None if v is None else np.array(v, copy=True))
+        return g
+
+    @property
+    def C(self):
+        return self.w.shape[0]
+
+    @property
+    def D(self):
+        return self.mu.shape[1]
+
+    def refresh(self):
+        """det, cst and the data independent term A (sidekit/mixture.py:382-396)."""
+        dim = self.mu.shape[1]
+        self.det = 1.0 / np.prod(self.invcov, axis=1)
+        self.cst = 1.0 / (np.sqrt(self.det) * (2.0 * np.pi) ** (dim / 2.0))
+        self.A = (np.square(self.mu) * self.invcov).sum(1) - 2.0 * (np.log(self.w) + np.log(self.cst))
+
+
+# ----------------------------------------------------------------------------------------
+# E-step pieces
+# ----------------------------------------------------------------------------------------
+def log_posterior(gmm, cep, mu=None):
+    """Weighted per-component log-likelihoods, T x C (sidekit/mixture.py:461-487)."""
+    cep = np.asarray(cep, dtype=F64)
+    if cep.ndim == 1:
+        cep = cep[None, :]
+    A = gmm.A
+    m = gmm.mu
+    if mu is not None:
+        m = np.asarray(mu, dtype=F64).reshape(gmm.mu.shape)
+        A = (np.square(m) * gmm.invcov).sum(1) - 2.0 * (np.log(gmm.w) + np.log(gmm.cst))
+    B = np.dot(np.square(cep), gmm.invcov.T) - 2.0 * np.dot(cep, (m * gmm.invcov).T)
+    return -0.5 * (B + A)
+
+
+def logsumexp_rows(lp):
+    """Row-wise log-sum-exp and posteriors.
+
+    Returns (pp, log_lk) with log_lk per row (sidekit/statserver.py:83-95); the Mixture
+    flavour (sidekit/mixture.py:52-64) returns log_lk.sum() instead.
+    Rows whose max is not finite keep log_lk = max (mixture.py:59-61).
+    """
+    top = np.max(lp, axis=1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        log_lk = top + np.log(np.sum(np.exp(lp - top[:, None]), axis=1))
+        bad = ~np.isfinite(top)
+        if bad.any():
+            log_lk[bad] = top[bad]
+        pp = np.exp(lp - log_lk[:, None])
+    return pp, log_lk
+
+
+def expectation(gmm, cep):
+    """One E-step over a block of frames (sidekit/mixture.py:537-568).
+
+    Returns zero/first/second order statistics N[C], F[C,D], S[C,D] and the summed
+    log-likelihood.
+    """
+    cep = np.asarray(cep, dtype=F64)
+    lp = log_posterior(gmm, cep)
+    pp, log_lk = logsumexp_rows(lp)
+    N = pp.sum(0)
+    F = np.dot(cep.T, pp).T
+    S = np.dot(np.square(cep.T), pp).T
+    return N, F, S, float(log_lk.sum())
+
+
+def expectation_chunked(gmm, chunks):
+    """E-step over a list of frame blocks, accumulating like mixture.py:584-588."""
+    C, D = gmm.C, gmm.D
+    N = np.zeros(C)
+    F = np.zeros((C, D))
+    S = np.zeros((C, D))
+    llk = 0.0
+    for cep in chunks:
+        n, f, s, l = expectation(gmm, cep)
+        N += n
+        F += f
+        S += s
+        llk += l
+    return N, F, S, llk
+
+
+# ----------------------------------------------------------------------------------------
+# M-step, split, init
+# ----------------------------------------------------------------------------------------
+def variance_control(cov, flooring, ceiling, cov_ctl):
+    """Floor / ceil a covariance with inclusive comparisons (sidekit/mixture.py:489-506)."""
+    floor = flooring * cov_ctl
+    ceil = ceiling * cov_ctl
+    lo = cov <= floor
+    hi = cov >= ceil
+    cov = cov.copy()
+    cov[lo] = floor[lo]
+    cov[hi] = ceil[hi]
+    return cov
+
+
+def maximization(gmm, N, F, S, ceil_cov=10, floor_cov=1e-2):
+    """M-step in place on `gmm` (sidekit/mixture.py:590-611)."""
+    gmm.w = N / np.sum(N)
+    gmm.mu = F / N[:, None]
+    cov = S / N[:, None] - np.square(gmm.mu)
+    cov = variance_control(cov, floor_cov, ceil_cov, gmm.cov_var_ctl)
+    gmm.invcov = 1.0 / cov
+    gmm.refresh()
+    return gmm
+
+
+def split(gmm):
+    """C -> 2C along the largest-variance axis (sidekit/mixture.py:517-535)."""
+    sigma = 1.0 / gmm.invcov
+    top = np.max(sigma, axis=1)
+    axis = np.argmax(sigma, axis=1)
+    shift = np.zeros(gmm.mu.shape)
+    shift[np.arange(axis.shape[0]), axis] = np.sqrt(top)
+    gmm.mu = np.vstack((gmm.mu - shift, gmm.mu + shift))
+    gmm.invcov = np.vstack((gmm.invcov, gmm.invcov))
+    gmm.w = np.concatenate([gmm.w, gmm.w]) * 0.5
+    gmm.cov_var_ctl = np.vstack((gmm.cov_var_ctl, gmm.cov_var_ctl))
+    gmm.refresh()
+    return gmm
+
+
+def init_single(features):
+    """1-Gaussian start; covariance is the raw second moment (sidekit/mixture.py:629-641)."""
+    features = np.asarray(features, dtype=F64)
+    mu = features.mean(0)
+    cov = (features ** 2).mean(0)
+    return GMM(np.asarray([1.0]), mu[None], 1.0 / cov[None])
+
+
+def init_uniform(cep, distrib_nb):
+    """EM_uniform start (sidekit/mixture.py:796-824) including its quirks.
+
+    `end = max(start + 10, nb)` is always nb, rows i > 0 stack `cov` (not 1/cov) into
+    invcov, and mu stays 1-D when distrib_nb == 1 (in which case the reference cannot
+    run an E-step; we keep 2-D there because no caller reaches it).
+    """
+    cep = np.asarray(cep, dtype=F64)
+    nb = cep.shape[0]
+    w = np.full(distrib_nb, 1.0 / distrib_nb, "d")
+    mus, ics = [], []
+    for i in range(distrib_nb):
+        start = nb // distrib_nb * i
+        end = max(start + 10, nb)
+        mus.append(np.mean(cep[start:end, :], axis=0))
+        cov = (cep[start:end, :] ** 2).mean(0)
+        ics.append(1.0 / cov if i == 0 else cov)
+    return GMM(w, np.vstack(mus), np.vstack(ics))
+
+
+def em_split(chunks, distrib_nb, iterations=(1, 2, 2, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8),
+             ceil_cov=10, floor_cov=1e-2, trace=None):
+    """Binary-split EM (sidekit/mixture.py:643-733), num_thread=1 semantics.
+
+    `chunks` is the list of per-file frame blocks the features server would return.
+    Returns (gmm, llk list).  `trace`, if a list, receives a copy of the model after
+    every M-step.
+    """
+    gmm = init_single(np.vstack(chunks))
+    llk = []
+    for it in iterations[:int(np.log2(distrib_nb))]:
+        split(gmm)
+        for _ in range(it):
+            N, F, S, l = expectation_chunked(gmm, chunks)
+            llk.append(l / np.sum(N))
+            maximization(gmm, N, F, S, ceil_cov=ceil_cov, floor_cov=floor_cov)
+            if trace is not None:
+                trace.append(gmm.copy())
+    return gmm, llk
+
+
+def em_uniform(cep, distrib_nb, iteration_min=3, iteration_max=10, llk_gain=0.01, gmm=None):
+    """Plain EM from a uniform-slice start (sidekit/mixture.py:735-794)."""
+    cep = np.asarray(cep, dtype=F64)
+    if gmm is None:
+        gmm = init_uniform(cep, distrib_nb)
+    llk = []
+    for i in range(iteration_max):
+        N, F, S, l = expectation(gmm, cep)
+        llk.append(l / cep.shape[0])
+        maximization(gmm, N, F, S)
+        if i > 0:
+            gain = llk[-1] - llk[-2]
+            if gain < llk_gain and i >= iteration_min:
+                break
+    return gmm, llk
+
+
+# ----------------------------------------------------------------------------------------
+# Baum-Welch statistics
+# ----------------------------------------------------------------------------------------
+def accumulate_stat(gmm, sessions):
+    """Per-session zero / first order statistics (sidekit/statserver.py:633-667).
+
+    `sessions` is a list of (T_s x D) arrays already cut to start:stop and VAD-selected.
+    stat1 is component-major: index c*D + d.
+    """
+    C, D = gmm.C, gmm.D
+    stat0 = np.zeros((len(sessions), C))
+    stat1 = np.zeros((len(sessions), C * D))
+    for i, data in enumerate(sessions):
+        data = np.asarray(data, dtype=F64)
+        if data.shape[1] != D:
+            raise Exception('dimension of ubm and features differ: {:d} / {:d}'.format(D, data.shape[1]))
+        pp, _ = logsumexp_rows(log_posterior(gmm, data))
+        stat0[i] = pp.sum(0)
+        stat1[i] = np.dot(data.T, pp).T.reshape(C * D)
+    return stat0, stat1
+
+
+def whiten_stat1(stat0, stat1, mu_sv, sigma_sv):
+    """float64 centring + diagonal whitening (sidekit/statserver.py:690-697, 743-745)."""
+    C = stat0.shape[1]
+    D = stat1.shape[1] // C
+    index_map = np.repeat(np.arange(C), D)
+    out = stat1 - stat0[:, index_map] * mu_sv.astype(F64)
+    return out / np.sqrt(sigma_sv.astype(F64))
+
+
+# ----------------------------------------------------------------------------------------
+# Total variability
+# ----------------------------------------------------------------------------------------
+def whiten_inplace_like_reference(stat0, stat1, gmm):
+    """The in-place whitening at the top of e_on_batch (sidekit/factor_analyser.py:76-79).
+
+    stat1 keeps ITS OWN dtype: with float32 inputs (statistics read back from the
+    float32 HDF5 datasets, statserver.py:439-446) each of the two in-place updates is
+    computed in float64 and rounded to float32.
+    """
+    C = stat0.shape[1]
+    D = gmm.D
+    index_map = np.repeat(np.arange(C), D)
+    stat1 -= stat0[:, index_map] * gmm.mu.flatten()
+    stat1 *= np.sqrt(gmm.invcov.flatten())
+    return stat1
+
+
+def triu_pack_index(R):
+    return np.triu_indices(R)
+
+
+def e_on_batch(stat0, stat1, gmm, Fm):
+    """Posterior moments of the latent factor for a batch (sidekit/factor_analyser.py:52-92).
+
+    stat1 is whitened IN PLACE (dtype preserved).  Returns e_h (B x R) and e_hh
+    (B x R(R+1)/2, row-major upper triangle), both float64.
+    """
+    R = Fm.shape[1]
+    C = stat0.shape[1]
+    D = gmm.D
+    index_map = np.repeat(np.arange(C), D)
+    iu = np.triu_indices(R)
+    B = stat0.shape[0]
+    e_h = np.zeros((B, R))
+    e_hh = np.zeros((B, R * (R + 1) // 2))
+    whiten_inplace_like_reference(stat0, stat1, gmm)
+    for i in range(B):
+        inv_lambda = scipy.linalg.inv(np.eye(R) + (Fm.T * stat0[i, index_map]).dot(Fm))
+        aux = Fm.T.dot(stat1[i, :])
+        e_h[i] = np.dot(aux, inv_lambda)
+        e_hh[i] = (inv_lambda + np.outer(e_h[i], e_h[i]))[iu]
+    return e_h, e_hh
+
+
+def batch_split(nb_sessions, batch_size):
+    """Batch index lists (sidekit/factor_analyser.py:618-619)."""
+    batch_nb = int(np.floor(nb_sessions / float(batch_size) + 0.999))
+    return np.array_split(np.arange(nb_sessions), batch_nb)
+
+
+def tv_accumulate(stat0, stat1, gmm, Fm, batch_size=300):
+    """One TV E-step: accumulators _A (C x P), _C (R x CD), _R (P) (factor_analyser.py:604-651).
+
+    stat0 / stat1 are the stored statistics (float32 when they come from a file); they are
+    NOT modified (each batch is copied like an HDF5 read would).
+    """
+    R = Fm.shape[1]
+    C = stat0.shape[1]
+    P = R * (R + 1) // 2
+    _A = np.zeros((C, P))
+    _C = np.zeros((R, stat1.shape[1]))
+    _R = np.zeros(P)
+    for idx in batch_split(stat0.shape[0], batch_size):
+        s0 = np.array(stat0[idx, :], copy=True)
+        s1 = np.array(stat1[idx, :], copy=True)
+        e_h, e_hh = e_on_batch(s0, s1, gmm, Fm)
+        _A += s0.T.dot(e_hh)
+        _C += e_h.T.dot(s1)
+        _R += np.sum(e_hh, axis=0)
+    _R /= stat0.shape[0]
+    return _A, _C, _R
+
+
+def tv_mstep(_A, _C, _R, D, min_div=True):
+    """M-step + minimum divergence (sidekit/factor_analyser.py:653-665)."""
+    C, P = _A.shape
+    R = _C.shape[0]
+    iu = np.triu_indices(R)
+    Fm = np.zeros((C * D, R))
+    tmp = np.zeros((R, R))
+    for c in range(C):
+        tmp[iu] = tmp.T[iu] = _A[c, :]
+        Fm[c * D:(c + 1) * D, :] = scipy.linalg.solve(tmp, _C[:, c * D:(c + 1) * D]).T
+    if min_div:
+        rt = np.zeros((R, R))
+        rt[iu] = rt.T[iu] = _R
+        ch = scipy.linalg.cholesky(rt)          # upper factor (scipy default)
+        Fm = Fm.dot(ch)
+    return Fm
+
+
+def total_variability(stat0, stat1, gmm, tv_rank, nb_iter=20, min_div=True, tv_init=None,
+                      batch_size=300, trace=None):
+    """TV matrix EM (sidekit/factor_analyser.py:535-672).  tv_init is required for parity
+    (the reference draws from the unseeded global RNG otherwise, :587)."""
+    assert tv_init is not None and tv_init.shape[1] == tv_rank
+    Fm = np.array(tv_init, dtype=F64, copy=True)
+    for _ in range(nb_iter):
+        _A, _C, _R = tv_accumulate(stat0, stat1, gmm, Fm, batch_size)
+        Fm = tv_mstep(_A, _C, _R, gmm.D, min_div)
+        if trace is not None:
+            trace.append(Fm.copy())
+    return Fm
+
+
+def extract_ivectors(stat0, stat1, gmm, Fm, batch_size=300):
+    """i-vectors and diagonal uncertainty (sidekit/factor_analyser.py:131-164, 732-808)."""
+    R = Fm.shape[1]
+    S = stat0.shape[0]
+    iv = np.zeros((S, R))
+    iv_sigma = np.zeros((S, R))
+    diag_idx = np.array([i * R - ((i * (i - 1)) // 2) for i in range(R)])
+    for idx in batch_split(S, batch_size):
+        s0 = np.array(stat0[idx, :], copy=True)
+        s1 = np.array(stat1[idx, :], copy=True)
+        e_h, e_hh = e_on_batch(s0, s1, gmm, Fm)
+        iv[idx, :] = e_h
+        iv_sigma[idx, :] = e_hh[:, diag_idx]
+    return iv, iv_sigma
+
+
+# ----------------------------------------------------------------------------------------
+# Synthetic data shared by tests, golden generation and the bench
+# ----------------------------------------------------------------------------------------
+def synth_frames(n, dim=60, clusters=64, seed=1234, dtype=np.float32):
+    """CMVN-like MFCC frames from a fixed random diagonal GMM."""
+    rs = np.random.RandomState(seed)
+    means = rs.randn(clusters, dim)
+    std = np.sqrt(rs.uniform(0.3, 1.0, size=(clusters, dim)))
+    lab = rs.randint(0, clusters, size=n)
+    x = means[lab] + std[lab] * rs.randn(n, dim)
+    return np.ascontiguousarray(x.astype(dtype))
+
+
+def random_gmm(C, D, seed=7):
+    """A valid random UBM: w ~ Dirichlet(5), mu ~ N(0,1), var ~ U(0.5,1.5)."""
+    rs = np.random.RandomState(seed)
+    w = rs.dirichlet(np.full(C, 5.0))
+    mu = rs.randn(C, D)
+    var = rs.uniform(0.5, 1.5, size=(C, D))
+    return GMM(w, mu, 1.0 / var)

@@ -1,0 +1,144 @@
+"""The CPU oracle (oracle/sidekit_ref.py) against golden vectors produced by the real
+reference (tools/gen_golden.py).  This is what pins the oracle; tolerance 1e-10 relative
+(float64 vs float64, only summation order may differ)."""
+import numpy as np
+import pytest
+
+from oracle import sidekit_ref as orc
+from conftest import golden
+
+RT = 1e-10
+
+
+def close(a, b, rtol=RT, atol=0.0):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(np.abs(b).max(), 1e-300)
+    err = np.abs(a - b).max() / scale
+    assert err <= rtol + atol, "normwise-max rel err %.3e" % err
+
+
+@pytest.mark.parametrize("tag", ["c8_d6", "c64_d60", "c40_d13"])
+def test_estep_mstep_split(tag):
+    g = golden("estep_%s.npz" % tag)
+    gmm = orc.GMM(g["w"], g["mu"], g["invcov"])
+    close(gmm.cst, g["cst"])
+    close(gmm.det, g["det"])
+    close(gmm.A, g["A"])
+    lp = orc.log_posterior(gmm, g["cep"])
+    pp, log_lk = orc.logsumexp_rows(lp)
+    close(log_lk, g["log_lk"])
+    if "lp" in g.files:
+        close(lp, g["lp"])
+        close(pp, g["pp"])
+    N, F, S, llk = orc.expectation(gmm, g["cep"])
+    close(N, g["N"])
+    close(F, g["F"])
+    close(S, g["S"])
+    assert abs(llk - float(g["llk"])) <= 1e-10 * abs(float(g["llk"]))
+    orc.maximization(gmm, N, F, S)
+    close(gmm.w, g["m_w"])
+    close(gmm.mu, g["m_mu"])
+    close(gmm.invcov, g["m_invcov"])
+    close(gmm.A, g["m_A"])
+    orc.split(gmm)
+    close(gmm.w, g["s_w"])
+    close(gmm.mu, g["s_mu"])
+    close(gmm.invcov, g["s_invcov"])
+    close(gmm.cov_var_ctl, g["s_ctl"])
+    close(gmm.A, g["s_A"])
+
+
+def test_em_split_full_schedule():
+    g = golden("em_split.npz")
+    chunks = [g["chunk%d" % i] for i in range(4)]
+    init = orc.init_single(np.vstack(chunks))
+    close(init.w, g["i_w"])
+    close(init.mu, g["i_mu"])
+    close(init.invcov, g["i_invcov"])
+    close(init.cov_var_ctl, g["i_ctl"])
+    gmm, llk = orc.em_split(chunks, 8)
+    assert len(llk) == len(g["llk"]) == 5
+    close(np.array(llk), g["llk"], rtol=1e-9)
+    close(gmm.w, g["w"], rtol=1e-8)
+    close(gmm.mu, g["mu"], rtol=1e-8)
+    close(gmm.invcov, g["invcov"], rtol=1e-8)
+    close(gmm.cov_var_ctl, g["ctl"])
+
+
+def test_em_uniform():
+    g = golden("em_uniform.npz")
+    init = orc.init_uniform(g["cep"], 4)
+    close(init.w, g["i_w"])
+    close(init.mu, g["i_mu"])
+    close(init.invcov, g["i_invcov"])
+    close(init.cov_var_ctl, g["i_ctl"])
+    gmm, llk = orc.em_uniform(g["cep"], 4)
+    assert len(llk) == len(g["llk"])
+    close(np.array(llk), g["llk"], rtol=1e-9)
+    close(gmm.w, g["w"], rtol=1e-8)
+    close(gmm.mu, g["mu"], rtol=1e-8)
+    close(gmm.invcov, g["invcov"], rtol=1e-8)
+
+
+def _sessions(g):
+    off = np.concatenate([[0], np.cumsum(g["lens"])])
+    return [g["frames"][off[i]:off[i + 1]] for i in range(len(g["lens"]))]
+
+
+def test_accumulate_stat():
+    g = golden("accumulate_stat.npz")
+    gmm = orc.GMM(g["w"], g["mu"], g["invcov"])
+    stat0, stat1 = orc.accumulate_stat(gmm, _sessions(g))
+    close(stat0, g["stat0"])
+    close(stat1, g["stat1"])
+
+
+def test_accumulate_stat_dim_mismatch():
+    g = golden("accumulate_stat.npz")
+    gmm = orc.GMM(g["w"], g["mu"], g["invcov"])
+    with pytest.raises(Exception):
+        orc.accumulate_stat(gmm, [np.zeros((5, gmm.D + 1))])
+
+
+def test_e_on_batch_and_tv():
+    g = golden("tv.npz")
+    gmm = orc.GMM(g["w"], g["mu"], g["invcov"])
+    s0 = g["stat0_f32"][:9].copy()
+    s1 = g["stat1_f32"][:9].copy()
+    assert s1.dtype == np.float32
+    e_h, e_hh = orc.e_on_batch(s0, s1, gmm, g["tv_init"])
+    assert s1.dtype == np.float32
+    np.testing.assert_array_equal(s1, g["eob_whitened"])      # float32 in-place whitening is bit exact
+    close(e_h, g["eob_e_h"])
+    close(e_hh, g["eob_e_hh"])
+    F1 = orc.total_variability(g["stat0_f32"], g["stat1_f32"], gmm, 6, nb_iter=1, tv_init=g["tv_init"], batch_size=7)
+    close(F1, g["F_it1"], rtol=1e-9)
+    F3 = orc.total_variability(g["stat0_f32"], g["stat1_f32"], gmm, 6, nb_iter=3, tv_init=g["tv_init"], batch_size=7)
+    close(F3, g["F_it3"], rtol=1e-8)
+    close(F3, g["F_it3_pool"], rtol=1e-8)
+    F2 = orc.total_variability(g["stat0_f32"], g["stat1_f32"], gmm, 6, nb_iter=2, min_div=False,
+                               tv_init=g["tv_init"], batch_size=7)
+    close(F2, g["F_it2_nomindiv"], rtol=1e-8)
+    iv, iv_sigma = orc.extract_ivectors(g["stat0_f32"], g["stat1_f32"], gmm, g["F_it3_pool"], batch_size=7)
+    close(iv, g["iv"], rtol=1e-9)
+    close(iv_sigma, g["iv_sigma"], rtol=1e-9)
+    assert g["iv_stat0"].shape == (iv.shape[0], 1) and np.all(g["iv_stat0"] == 1.0)
+    assert np.all(g["fa_mean"] == 0) and np.all(g["fa_sigma"] == 0)
+
+
+def test_whiten_f64_matches_single_path():
+    g = golden("tv.npz")
+    gmm = orc.GMM(g["w"], g["mu"], g["invcov"])
+    s0 = g["stat0_f32"].astype(np.float64)
+    s1 = g["stat1_f32"].astype(np.float64)
+    w = orc.whiten_stat1(s0, s1, gmm.mu.flatten(), 1.0 / gmm.invcov.flatten())
+    R = g["F_it3_pool"].shape[1]
+    Fm = g["F_it3_pool"]
+    idx = np.repeat(np.arange(gmm.C), gmm.D)
+    iv = np.zeros((s0.shape[0], R))
+    for i in range(s0.shape[0]):
+        L = np.eye(R) + (Fm.T * s0[i, idx]).dot(Fm)
+        iv[i] = np.linalg.solve(L, Fm.T.dot(w[i]))
+    close(iv, g["iv_single"], rtol=1e-9)

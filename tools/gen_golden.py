@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (runs only in the build container).
+
+The reference (/root/reference, SIDEKIT 1.3.2 fork) is imported read-only with
+`sys.dont_write_bytecode`, exercised on small seeded inputs with `num_thread=1`, and only
+input/output ARRAYS are written to tests/golden/*.npz.  No reference source, bytecode or
+derivative travels with the repo.  The recipe follows SURVEY.md Appendix A:
+
+* `h5py` is not installed: a dict-of-ndarrays stand-in is registered in sys.modules so that
+  `import sidekit` succeeds and the file-based drivers (StatServer.write, total_variability,
+  extract_ivectors) can round-trip through "files";
+* matplotlib 3.10 rejects `matplotlib.use(..., warn=False)` in bosaris/detplot.py:39.
+
+Usage:  SIDEKIT=libsvm=false python3 -W ignore tools/gen_golden.py
+"""
+import os
+import sys
+import types
+import pickle
+import tempfile
+
+os.environ.setdefault("SIDEKIT", "libsvm=false")
+sys.dont_write_bytecode = True
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+
+# ------------------------------------------------------------------ h5py stand-in
+class _DS(object):
+    def __init__(self, arr):
+        self.arr = np.asarray(arr)
+
+    @property
+    def value(self):
+        return self.arr
+
+    @property
+    def shape(self):
+        return self.arr.shape
+
+    def __getitem__(self, k):
+        return self.arr[k]
+
+    def __setitem__(self, k, v):
+        self.arr[k] = v
+
+    def resize(self, shape):
+        new = np.zeros(shape, dtype=self.arr.dtype)
+        sl = tuple(slice(0, min(a, b)) for a, b in zip(self.arr.shape, shape))
+        new[sl] = self.arr[sl]
+        self.arr = new
+
+
+class _File(object):
+    def __init__(self, name, mode="r"):
+        self.name, self.mode = name, mode
+        self.d = {}
+        if mode in ("r", "a", "r+") and os.path.exists(name):
+            with open(name, "rb") as f:
+                self.d = {k: _DS(v) for k, v in pickle.load(f).items()}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def close(self):
+        if self.mode != "r":
+            with open(self.name, "wb") as f:
+                pickle.dump({k: v.arr for k, v in self.d.items()}, f)
+
+    def create_dataset(self, name, shape=None, dtype=None, data=None, **kw):
+        arr = np.zeros(shape, dtype=dtype) if data is None else np.array(data)
+        self.d[name] = _DS(arr)
+        return self.d[name]
+
+    def __getitem__(self, k):
+        return self.d[k]
+
+    def get(self, k):
+        return self.d.get(k)
+
+    def __contains__(self, k):
+        return k in self.d
+
+    def keys(self):
+        return self.d.keys()
+
+
+def import_reference():
+    fake = types.ModuleType("h5py")
+    fake.File = _File
+    sys.modules["h5py"] = fake
+    import matplotlib
+    matplotlib.use = lambda *a, **k: None
+    sys.path.insert(0, REF)
+    import sidekit
+    return sidekit
+
+
+sys.path.insert(0, ROOT)
+from oracle import sidekit_ref as orc  # only for the shared synthetic-data helpers
+
+
+def make_ubm(sidekit, w, mu, invcov):
+    m = sidekit.Mixture()
+    m.w = np.array(w, dtype="d")
+    m.mu = np.array(mu, dtype="d")
+    m.invcov = np.array(invcov, dtype="d")
+    m.cov_var_ctl = 1.0 / m.invcov
+    m.cst = np.zeros(m.w.shape)
+    m.det = np.zeros(m.w.shape)
+    m._compute_all()
+    return m
+
+
+def mem_server(sidekit, table):
+    """In-memory FeaturesServer (must subclass: isinstance assert at statserver.py:623)."""
+    class Mem(sidekit.FeaturesServer):
+        def __init__(self):
+            super().__init__(dataset_list=["cep"])
+            self.table = table
+
+        def load(self, show, channel=0, input_feature_filename=None, label=None, start=None, stop=None):
+            x = self.table[show]
+            return x, np.ones(x.shape[0], dtype=bool)
+
+        def stack_features_parallel(self, show_list, num_thread=1, **kw):
+            return np.vstack([self.table[s] for s in show_list])
+    return Mem()
+
+
+def gen_estep(sidekit, tag, C, D, T, seed):
+    g = orc.random_gmm(C, D, seed=seed)
+    cep = orc.synth_frames(T, dim=D, clusters=max(4, C // 2), seed=seed + 1, dtype=np.float64)
+    ubm = make_ubm(sidekit, g.w, g.mu, g.invcov)
+    lp = ubm.compute_log_posterior_probabilities(cep)
+    pp, llk = sidekit.mixture.sum_log_probabilities(lp)
+    pp2, log_lk = sidekit.statserver.sum_log_probabilities(lp)
+    import copy
+    accum = copy.deepcopy(ubm)
+    accum._reset()
+    llk2 = ubm._expectation(accum, cep)
+    out = dict(w=ubm.w, mu=ubm.mu, invcov=ubm.invcov, cst=ubm.cst, det=ubm.det, A=ubm.A, cep=cep,
+               N=accum.w.copy(), F=accum.mu.copy(), S=accum.invcov.copy(), llk=np.float64(llk2),
+               log_lk=log_lk)
+    if T * C <= 40000:
+        out["lp"] = lp
+        out["pp"] = pp
+    new = copy.deepcopy(ubm)
+    new._maximization(accum)
+    out.update(m_w=new.w, m_mu=new.mu, m_invcov=new.invcov, m_cst=new.cst, m_det=new.det, m_A=new.A)
+    sp = copy.deepcopy(new)
+    sp._split_ditribution()
+    out.update(s_w=sp.w, s_mu=sp.mu, s_invcov=sp.invcov, s_ctl=sp.cov_var_ctl, s_A=sp.A)
+    np.savez_compressed(os.path.join(OUT, "estep_%s.npz" % tag), **out)
+    print("estep", tag, "llk", llk2)
+
+
+def gen_em_split(sidekit):
+    rs = np.random.RandomState(11)
+    D, K = 6, 8
+    centers = rs.randn(K, D) * 6.0
+    chunks = {}
+    for i in range(4):
+        lab = rs.randint(0, K, size=500 + 37 * i)
+        chunks["f%d" % i] = centers[lab] + 0.5 * rs.randn(lab.shape[0], D)
+    fs = mem_server(sidekit, chunks)
+    ubm = sidekit.Mixture()
+    llk = ubm.EM_split(features_server=fs, feature_list=list(chunks.keys()), distrib_nb=8, num_thread=1,
+                       save_partial=False)
+    out = {"chunk%d" % i: chunks["f%d" % i] for i in range(4)}
+    out.update(llk=np.array(llk), w=ubm.w, mu=ubm.mu, invcov=ubm.invcov, ctl=ubm.cov_var_ctl, A=ubm.A)
+    # init only
+    u0 = sidekit.Mixture()
+    u0._init(fs, list(chunks.keys()), 1)
+    out.update(i_w=u0.w, i_mu=u0.mu, i_invcov=u0.invcov, i_ctl=u0.cov_var_ctl, i_A=u0.A)
+    np.savez_compressed(os.path.join(OUT, "em_split.npz"), **out)
+    print("em_split llk", llk[-3:], "iters", len(llk))
+
+
+def gen_em_uniform(sidekit):
+    rs = np.random.RandomState(21)
+    D, K = 5, 4
+    centers = rs.randn(K, D) * 4.0
+    lab = rs.randint(0, K, size=1500)
+    cep = centers[lab] + 0.7 * rs.randn(1500, D)
+    ubm = sidekit.Mixture()
+    llk = ubm.EM_uniform(cep, 4, iteration_min=3, iteration_max=10, llk_gain=0.01, do_init=True)
+    out = dict(cep=cep, llk=np.array(llk), w=ubm.w, mu=ubm.mu, invcov=ubm.invcov, ctl=ubm.cov_var_ctl)
+    u0 = sidekit.Mixture()
+    u0._init_uniform(cep, 4)
+    out.update(i_w=u0.w, i_mu=u0.mu, i_invcov=u0.invcov, i_ctl=u0.cov_var_ctl)
+    np.savez_compressed(os.path.join(OUT, "em_uniform.npz"), **out)
+    print("em_uniform llk", llk)
+
+
+def gen_stats_and_tv(sidekit, tmp):
+    C, D, R = 16, 10, 6
+    g = orc.random_gmm(C, D, seed=31)
+    ubm = make_ubm(sidekit, g.w, g.mu, g.invcov)
+    rs = np.random.RandomState(32)
+    lens = [1, 7, 33, 64, 100, 257] + list(rs.randint(40, 300, size=34))
+    S = len(lens)
+    table = {}
+    for i, L in enumerate(lens):
+        table["s%03d" % i] = orc.synth_frames(L, dim=D, clusters=8, seed=100 + i, dtype=np.float64)
+    fs = mem_server(sidekit, table)
+    idmap = sidekit.IdMap()
+    idmap.leftids = np.array(["spk%d" % (i % 5) for i in range(S)])
+    idmap.rightids = np.array(sorted(table.keys()))
+    idmap.start = np.empty(S, "|O")
+    idmap.stop = np.empty(S, "|O")
+    ss = sidekit.StatServer(idmap, ubm=ubm)
+    ss.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(S), num_thread=1)
+    out = dict(w=ubm.w, mu=ubm.mu, invcov=ubm.invcov, lens=np.array(lens),
+               frames=np.vstack([table[k] for k in sorted(table.keys())]),
+               stat0=ss.stat0.copy(), stat1=ss.stat1.copy())
+    np.savez_compressed(os.path.join(OUT, "accumulate_stat.npz"), **out)
+    print("accumulate_stat", ss.stat0.shape, ss.stat1.shape)
+
+    # --- TV: statistics go through the float32 "HDF5" file like i-vector.py does
+    stat_file = os.path.join(tmp, "stat.h5")
+    ss.write(stat_file)
+    s0_32 = ss.stat0.astype(np.float32)
+    s1_32 = ss.stat1.astype(np.float32)
+    tv_init = 0.1 * np.random.RandomState(7).randn(C * D, R)
+
+    from sidekit.factor_analyser import e_on_batch
+    a0, a1 = s0_32[:9].copy(), s1_32[:9].copy()
+    e_h, e_hh = e_on_batch(a0, a1, ubm, tv_init.copy())
+    tv = dict(w=ubm.w, mu=ubm.mu, invcov=ubm.invcov, stat0_f32=s0_32, stat1_f32=s1_32, tv_init=tv_init,
+              eob_e_h=e_h, eob_e_hh=e_hh, eob_whitened=a1)
+
+    for nit, key in ((1, "F_it1"), (3, "F_it3")):
+        fa = sidekit.FactorAnalyser()
+        fa.total_variability_single(stat_file, ubm, R, nb_iter=nit, min_div=True, tv_init=tv_init.copy(),
+                                    batch_size=7, save_init=False, output_file_name=None)
+        tv[key] = fa.F.copy()
+    fa_nomd = sidekit.FactorAnalyser()
+    fa_nomd.total_variability_single(stat_file, ubm, R, nb_iter=2, min_div=False, tv_init=tv_init.copy(),
+                                     batch_size=7, save_init=False, output_file_name=None)
+    tv["F_it2_nomindiv"] = fa_nomd.F.copy()
+
+    # pooled driver (the north-star entry point) -- must equal _single
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        fa2 = sidekit.FactorAnalyser()
+        fa2.total_variability(stat_file, ubm, R, nb_iter=3, min_div=True, tv_init=tv_init.copy(),
+                              batch_size=7, save_init=False, output_file_name=os.path.join(tmp, "tv"),
+                              num_thread=1)
+        tv["F_it3_pool"] = fa2.F.copy()
+        tv["fa_mean"] = fa2.mean
+        tv["fa_sigma"] = fa2.Sigma
+        ivs, iv_sigma = fa2.extract_ivectors(ubm, stat_file, prefix="", batch_size=7, uncertainty=True,
+                                             num_thread=1)
+        tv["iv"] = ivs.stat1.copy()
+        tv["iv_stat0"] = ivs.stat0.copy()
+        tv["iv_sigma"] = iv_sigma.copy()
+        # single-process extraction (float64 whitening path)
+        ss2 = sidekit.StatServer(stat_file)
+        ivs2, sig2 = fa2.extract_ivectors_single(ubm, ss2, uncertainty=True)
+        tv["iv_single"] = ivs2.stat1.copy()
+        tv["iv_sigma_single"] = sig2.copy()
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "tv.npz"), **tv)
+    print("tv |F_it3 - F_it3_pool| =", np.abs(tv["F_it3"] - tv["F_it3_pool"]).max(),
+          " |iv - iv_single| =", np.abs(tv["iv"] - tv["iv_single"]).max())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    sidekit = import_reference()
+    print("reference sidekit", getattr(sidekit, "__version__", "?"), "STAT_TYPE", sidekit.STAT_TYPE)
+    gen_estep(sidekit, "c8_d6", C=8, D=6, T=300, seed=3)
+    gen_estep(sidekit, "c64_d60", C=64, D=60, T=2000, seed=5)
+    gen_estep(sidekit, "c40_d13", C=40, D=13, T=777, seed=9)
+    gen_em_split(sidekit)
+    gen_em_uniform(sidekit)
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_stats_and_tv(sidekit, tmp)
+
+
+if __name__ == "__main__":
+    main()
