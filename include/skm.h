@@ -1,0 +1,98 @@
+/*
+ * skm.h -- C ABI of libskm.so: the MI355X (gfx950) implementation of SIDEKIT's GMM-UBM /
+ * i-vector sufficient-statistics hot path.
+ *
+ * The reference (Anwarvic/Speaker-Recognition = SIDEKIT 1.3.2) has no FFI for this path: it
+ * is NumPy called from Python methods.  Each entry point below names the
+ * reference call site(s) whose arithmetic it replaces; the Python classes in
+ * speaker-recognition_amd/ (Mixture, StatServer, FactorAnalyser) keep the reference's method
+ * surface and call these through ctypes.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative code otherwise; skm_last_error() gives
+ *     the message of the last failure on the calling thread;
+ *   - "dev" pointers are device (HBM) addresses on the ctx's GPU, "host" pointers are ordinary
+ *     host memory; the library never frees or keeps caller buffers;
+ *   - all work is enqueued on the hipStream_t passed as `stream` (NULL = default stream) and is
+ *     asynchronous unless stated; workspace sizes are queried, the launch functions allocate
+ *     nothing;
+ *   - float32 arithmetic on the MFMA units, float64 for every cross-tile reduction and output.
+ */
+#ifndef SKM_H
+#define SKM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKM_OK            0
+#define SKM_ERR_ARG      -1   /* bad argument (shape, alignment, NULL)            */
+#define SKM_ERR_HIP      -2   /* a HIP runtime call failed                         */
+#define SKM_ERR_WORKSPACE -3  /* workspace too small                               */
+#define SKM_ERR_UNSUPPORTED -4/* shape outside what the kernels were built for     */
+
+int         skm_version(void);
+const char *skm_last_error(void);
+
+/* One context per GPU: device id, CU count, launch geometry.  No device memory is owned. */
+int skm_ctx_create(int device, void **ctx);
+int skm_ctx_destroy(void *ctx);
+int skm_ctx_cu_count(void *ctx);
+
+/* ------------------------------------------------------------------ diagonal GMM ------ */
+
+/* Bytes of the packed, MFMA-fragment-ordered GMM image for C components of dimension D. */
+size_t skm_gmm_packed_bytes(int C, int D);
+
+/* Packs host float64 parameters (w[C], mu[C*D], invcov[C*D], row-major) into the device image
+ * used by every kernel below: [-1/2 invcov ; mu*invcov] in MFMA B-fragment order plus the per
+ * component constant -1/2 A_c, all pre-scaled by log2(e).
+ * Replaces Mixture._compute_all (sidekit/mixture.py:382-396) and the operand set-up of
+ * Mixture.compute_log_posterior_probabilities (sidekit/mixture.py:473-483).
+ * Synchronous with respect to `stream` on return (the host staging buffer is freed). */
+int skm_gmm_pack(void *ctx, const double *w_host, const double *mu_host, const double *invcov_host,
+                 int C, int D, void *packed_dev, void *stream);
+
+/* Workspace bytes for skm_gmm_estep / skm_gmm_loglik / skm_bw_stats over T frames. */
+size_t skm_gmm_workspace_bytes(void *ctx, long T, int C, int D);
+
+/* E-step of the EM over T frames X[T*D] (float32, row-major, dev):
+ *   out_dev = [ N[C] | F[C*D] | S[C*D] | llk ]  float64, (2*C*D + C + 1) values,
+ *   N = sum_t gamma, F = gamma^T X, S = gamma^T X^2, llk = sum_t log sum_c w_c N(x_t).
+ * accumulate != 0 adds to out_dev instead of overwriting it.
+ * Replaces Mixture._expectation (sidekit/mixture.py:537-568) = compute_log_posterior_probabilities
+ * (:461-487) + sum_log_probabilities (:52-64) + the three accumulations (:557-562), and the
+ * per-file loop of Mixture._expectation_list (:584-588). */
+int skm_gmm_estep(void *ctx, const float *X_dev, long T, int C, int D, const void *packed_dev,
+                  double *out_dev, int accumulate, void *ws_dev, size_t ws_bytes, void *stream);
+
+/* Per-frame log-likelihood log sum_c w_c N(x_t; mu_c, Sigma_c) (natural log, float32, dev).
+ * Replaces compute_log_posterior_probabilities + the log_lk of sum_log_probabilities
+ * (sidekit/statserver.py:83-95; used by gmm_scoring, sidekit/gmm_scoring.py:102-111). */
+int skm_gmm_loglik(void *ctx, const float *X_dev, long T, int C, int D, const void *packed_dev,
+                   float *loglik_dev, void *ws_dev, size_t ws_bytes, void *stream);
+
+/* Baum-Welch statistics per session.  Session s owns frames [seg_off[s], seg_off[s+1]) of X
+ * (seg_off: S+1 int64 on the device, non-decreasing, seg_off[S] <= T).
+ *   stat0_dev[S*C]      float64   zero order  (sum_t gamma)
+ *   stat1_dev[S*C*D]    float64   first order, component-major (index c*D + d)
+ * Rows of empty sessions are set to zero.
+ * Replaces the body of StatServer.accumulate_stat (sidekit/statserver.py:659-667). */
+int skm_bw_stats(void *ctx, const float *X_dev, long T, const int64_t *seg_off_dev, int S, int C, int D,
+                 const void *packed_dev, double *stat0_dev, double *stat1_dev,
+                 void *ws_dev, size_t ws_bytes, void *stream);
+
+/* Column sums of X and X^2 over T frames: out_dev = [ sum x (D) | sum x^2 (D) ] float64.
+ * Replaces the two reductions of Mixture._init (sidekit/mixture.py:631-632).
+ * ws_dev needs skm_moments_workspace_bytes(ctx, D) bytes. */
+size_t skm_moments_workspace_bytes(void *ctx, int D);
+int skm_moments(void *ctx, const float *X_dev, long T, int D, double *out_dev,
+                void *ws_dev, size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKM_H */

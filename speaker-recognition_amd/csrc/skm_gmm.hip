@@ -1,0 +1,937 @@
+// skm_gmm.hip -- diagonal-GMM E-step / Baum-Welch statistics for gfx950 (MI355X).
+//
+// Replaces (reference = SIDEKIT 1.3.2 fork, paths relative to its root):
+//   sidekit/mixture.py:461-487   compute_log_posterior_probabilities  (2 GEMMs T x D x C)
+//   sidekit/mixture.py:52-64     sum_log_probabilities                (row logsumexp, posteriors)
+//   sidekit/mixture.py:537-568   _expectation                         (N, F, S accumulation)
+//   sidekit/statserver.py:659-667 accumulate_stat body                (per-session N, F)
+//   sidekit/mixture.py:631-632   _init moments
+//
+// Formulation.  With x~ = [x, x^2] and per component the packed columns
+//   Wlin = log2e * mu*invcov,  Wsq = -1/2 log2e * invcov,  kc = log2e * (log w + log cst - 1/2 sum mu^2 invcov)
+// the base-2 logit is  l[t,c] = kc[c] + x~[t,:] . W[:,c]  (one f32 MFMA GEMM, K = 2D).
+// gamma[t,c] = exp2(l[t,c] - lse[t]) needs the row logsumexp over ALL components, while the
+// statistics sum gamma over ALL frames, so the path runs as two sweeps over the frames:
+//   sweep 1  k_lse_partial : per (component block, frame) partial (max, sum exp2) -> k_lse_combine -> lse[t]
+//   sweep 2  k_stats       : recompute l - lse, gamma = exp2(.), [N|F|S] += gamma^T [1, x, x^2]  (second MFMA GEMM,
+//                            the accumulator tile of GEMM 1 is fed straight back as the A operand of GEMM 2)
+// Both sweeps keep their component block's W resident in LDS for the life of the workgroup, stage 32-frame
+// tiles of X through wave-private LDS, and never write a T x C matrix to HBM.
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (exact f32, 64 cycles/SIMD).  Operand maps (lane l, c = l&31, h = l>>5):
+//   A[i=c][k=h], B[k=h][j=c], D[row = (r&3) + 8*(r>>2) + 4*h][col = c], r = accumulator register 0..15.
+#include "skm_common.h"
+
+#include <stdarg.h>
+
+// ------------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void skm_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *skm_last_error(void) { return g_err; }
+extern "C" int skm_version(void) { return 100; }
+
+extern "C" int skm_ctx_create(int device, void **ctx)
+{
+    SKM_REQUIRE(ctx != nullptr, "skm_ctx_create: ctx is NULL");
+    int n = 0;
+    SKM_HIP(hipGetDeviceCount(&n));
+    SKM_REQUIRE(device >= 0 && device < n, "skm_ctx_create: device %d out of range (%d visible)", device, n);
+    hipDeviceProp_t prop;
+    SKM_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        skm_set_error("skm_ctx_create: device %d is %s, this library is built for gfx950 only", device,
+                      prop.gcnArchName);
+        return SKM_ERR_UNSUPPORTED;
+    }
+    SkmCtx *c = new SkmCtx();
+    c->device = device;
+    c->cu_count = prop.multiProcessorCount;
+    *ctx = c;
+    return SKM_OK;
+}
+
+extern "C" int skm_ctx_destroy(void *ctx)
+{
+    delete static_cast<SkmCtx *>(ctx);
+    return SKM_OK;
+}
+
+extern "C" int skm_ctx_cu_count(void *ctx) { return ctx ? static_cast<SkmCtx *>(ctx)->cu_count : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+#define SKM_LDS_BUDGET (160 * 1024)
+#define SKM_FLUSH_TILES 256  // f32 MFMA accumulators are folded into f64 every 8192 frames
+
+struct TileGeom {
+    int D, XS, NG, NP, tail;
+    int vec4;  // 1: rows are 16-byte aligned (D % 4 == 0 and X 16-byte aligned)
+};
+
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Columns D..XS-1 of the wave's staged tile never change: column D is the ones column that
+// makes the statistics GEMM emit N, the rest is zero.
+__device__ __forceinline__ void init_tile_padding(float *xs, const TileGeom &g, int lane)
+{
+    const int padw = g.XS - g.D;
+    for (int i = lane; i < 32 * padw; i += 64) {
+        const int row = i / padw, col = g.D + (i - row * padw);
+        xs[row * g.XS + col] = (col == g.D) ? 1.0f : 0.0f;
+    }
+}
+
+// Stage frames [t0, t0+32) (rows >= nvalid zero-filled) into xs[32][XS].
+// A 32-frame tile is one contiguous span of 32*D floats of X: fully coalesced loads.
+__device__ __forceinline__ void stage_tile(float *xs, const float *__restrict__ X, long t0, int nvalid,
+                                           const TileGeom &g, int lane)
+{
+    if (g.vec4) {
+        const int n4 = g.D >> 2;
+        const f32x4 *X4 = reinterpret_cast<const f32x4 *>(X + t0 * (long)g.D);
+        int row = lane / n4, c4 = lane - row * n4;
+        const int rstep = 64 / n4, cstep = 64 - rstep * n4;
+        const int total = 32 * n4;
+        for (int e = lane; e < total; e += 64) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < nvalid) v = X4[e];
+            *reinterpret_cast<f32x4 *>(xs + row * g.XS + 4 * c4) = v;
+            row += rstep;
+            c4 += cstep;
+            if (c4 >= n4) {
+                c4 -= n4;
+                row++;
+            }
+        }
+    } else {
+        const int n = g.D;
+        const float *Xs = X + t0 * (long)g.D;
+        int row = lane / n, col = lane - row * n;
+        const int rstep = 64 / n, cstep = 64 - rstep * n;
+        const int total = 32 * n;
+        for (int e = lane; e < total; e += 64) {
+            float v = 0.f;
+            if (row < nvalid) v = Xs[e];
+            xs[row * g.XS + col] = v;
+            row += rstep;
+            col += cstep;
+            if (col >= n) {
+                col -= n;
+                row++;
+            }
+        }
+    }
+}
+
+// Order LDS traffic of ONE wave: DS operations of a wave execute in issue order, so only the
+// compiler has to be kept from moving reads above the writes of other lanes.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// GEMM 1: lg[ct] += x~ tile (32 frames x 2D) . W block.  xs_row = xs + c*XS, Wl4 = W block + lane.
+template <int NCT>
+__device__ __forceinline__ void gemm_logits(f32x16 (&lg)[NCT], const float *xs_row, int h, const f32x4 *Wl4,
+                                            const TileGeom &g)
+{
+    const float *xr = xs_row + 4 * h;
+    const int NG = g.NG;
+    for (int q = 0; q < g.NP; ++q) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(xr + 8 * q);
+        const f32x4 s4 = a4 * a4;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const f32x4 wl = Wl4[(ct * NG + 2 * q) * 64];
+            const f32x4 wq = Wl4[(ct * NG + 2 * q + 1) * 64];
+            lg[ct] = SKM_MFMA32(a4[0], wl[0], lg[ct]);
+            lg[ct] = SKM_MFMA32(a4[1], wl[1], lg[ct]);
+            lg[ct] = SKM_MFMA32(a4[2], wl[2], lg[ct]);
+            lg[ct] = SKM_MFMA32(a4[3], wl[3], lg[ct]);
+            lg[ct] = SKM_MFMA32(s4[0], wq[0], lg[ct]);
+            lg[ct] = SKM_MFMA32(s4[1], wq[1], lg[ct]);
+            lg[ct] = SKM_MFMA32(s4[2], wq[2], lg[ct]);
+            lg[ct] = SKM_MFMA32(s4[3], wq[3], lg[ct]);
+        }
+    }
+    if (g.tail) {
+        f32x4 a4 = *reinterpret_cast<const f32x4 *>(xs_row + 8 * g.NP);
+        if (h) a4 = a4 * a4;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const f32x4 wm = Wl4[(ct * NG + NG - 1) * 64];
+            lg[ct] = SKM_MFMA32(a4[0], wm[0], lg[ct]);
+            lg[ct] = SKM_MFMA32(a4[1], wm[1], lg[ct]);
+            lg[ct] = SKM_MFMA32(a4[2], wm[2], lg[ct]);
+            lg[ct] = SKM_MFMA32(a4[3], wm[3], lg[ct]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sweep 1: per (component block, frame) partial max / sum of exp2
+// ------------------------------------------------------------------------------------------------
+struct LseArgs {
+    const float *X;
+    long T;
+    TileGeom g;
+    const float *wp;  // packed W  [CTpad][NG][64][4]
+    const float *kc;  // [CTpad*32]
+    float *pm;        // [n_cb][T]
+    float *ps;        // [n_cb][T]
+    int n_cb, n_fs;
+};
+
+template <int NCT>
+__global__ __launch_bounds__(512, 2) void k_lse_partial(LseArgs a)
+{
+    extern __shared__ __align__(16) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int cb = blockIdx.x % a.n_cb, fs = blockIdx.x / a.n_cb;
+    const TileGeom g = a.g;
+
+    float *Wl = smem;
+    const int wfloats = NCT * g.NG * 256;
+    float *xs = smem + wfloats + wave * (32 * g.XS + 32);
+
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wp) + (long)cb * (wfloats / 4);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(Wl);
+        for (int i = threadIdx.x; i < wfloats / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    init_tile_padding(xs, g, lane);
+    __syncthreads();
+
+    float kcv[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) kcv[ct] = a.kc[(cb * NCT + ct) * 32 + c];
+
+    const long tiles = (a.T + 31) >> 5;
+    const long slot = (long)fs * NW + wave, n_slots = (long)a.n_fs * NW;
+    const long ta = tiles * slot / n_slots, tb = tiles * (slot + 1) / n_slots;
+    const f32x4 *Wl4 = reinterpret_cast<const f32x4 *>(Wl) + lane;
+    float *pm = a.pm + (long)cb * a.T;
+    float *ps = a.ps + (long)cb * a.T;
+
+    for (long tile = ta; tile < tb; ++tile) {
+        const long t0 = tile << 5;
+        const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
+        stage_tile(xs, a.X, t0, nvalid, g, lane);
+        wave_lds_fence();
+
+        f32x16 lg[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lg[ct][r] = kcv[ct];
+
+        gemm_logits<NCT>(lg, xs + c * g.XS, h, Wl4, g);
+
+        // Row (= frame) reductions across the 32 component lanes of each half and the NCT tiles.
+        float mym = 0.f, mys = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float m = lg[0][r];
+#pragma unroll
+            for (int ct = 1; ct < NCT; ++ct) m = fmaxf(m, lg[ct][r]);
+#pragma unroll
+            for (int msk = 1; msk < 32; msk <<= 1) m = fmaxf(m, __shfl_xor(m, msk));
+            float s = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) s += __builtin_amdgcn_exp2f(lg[ct][r] - m);
+#pragma unroll
+            for (int msk = 1; msk < 32; msk <<= 1) s += __shfl_xor(s, msk);
+            if (c == r) {
+                mym = m;
+                mys = s;
+            }
+        }
+        if (c < 16) {
+            const int frame = acc_row(c, h);
+            if (frame < nvalid) {
+                pm[t0 + frame] = mym;
+                ps[t0 + frame] = mys;
+            }
+        }
+        wave_lds_fence();  // all reads of xs done before the next tile is staged
+    }
+}
+
+// lse[t] = log2 sum_c 2^l[t,c] from the per-block partials; block partial sums of lse*ln2 in f64.
+__global__ __launch_bounds__(256) void k_lse_combine(const float *__restrict__ pm, const float *__restrict__ ps,
+                                                     int n_cb, long T, float *__restrict__ lse2,
+                                                     float *__restrict__ loglik, double *__restrict__ llk_part)
+{
+    __shared__ double red[256];
+    double local = 0.0;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (long)gridDim.x * blockDim.x) {
+        float m = pm[t];
+        for (int b = 1; b < n_cb; ++b) m = fmaxf(m, pm[(long)b * T + t]);
+        float s = 0.f;
+        for (int b = 0; b < n_cb; ++b) s += ps[(long)b * T + t] * __builtin_amdgcn_exp2f(pm[(long)b * T + t] - m);
+        const float l2 = m + __builtin_amdgcn_logf(s);  // v_log_f32 is log2
+        if (lse2) lse2[t] = l2;
+        if (loglik) loglik[t] = l2 * 0.6931471805599453f;
+        local += (double)l2;
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && llk_part) llk_part[blockIdx.x] = red[0] * 0.6931471805599453094;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sweep 2: posteriors and statistics
+// ------------------------------------------------------------------------------------------------
+struct StatsArgs {
+    const float *X;
+    long T;
+    TileGeom g;
+    const float *wp;
+    const float *kc;
+    const float *lse2;  // [T] base-2 logsumexp
+    int n_cb, n_fs;
+    int C;
+    // EM mode: one f64 slab [NCT*32][NF*32] per wave slot
+    double *slabs;
+    // Baum-Welch mode
+    const int64_t *seg_off;
+    int S;
+    double *stat0;
+    double *stat1;
+};
+
+// One 32-frame tile: stage, logits - lse, gamma, statistics GEMM into acc.
+template <int NJT, int NCT, bool WITH_S>
+__device__ __forceinline__ void stats_tile(f32x16 (&acc)[NCT][NJT * (WITH_S ? 2 : 1)], float *xs, float *ls,
+                                           const float *__restrict__ X, const float *__restrict__ lse2, long t0,
+                                           int nvalid, const TileGeom &g, const f32x4 *Wl4,
+                                           const float (&kcv)[NCT], int lane)
+{
+    const int h = lane >> 5, c = lane & 31;
+    stage_tile(xs, X, t0, nvalid, g, lane);
+    if (lane < 32) ls[lane] = (lane < nvalid) ? lse2[t0 + lane] : 3.0e38f;
+    wave_lds_fence();
+
+    f32x16 lg[NCT];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            lg[ct][4 * q4 + 0] = kcv[ct] - l4[0];
+            lg[ct][4 * q4 + 1] = kcv[ct] - l4[1];
+            lg[ct][4 * q4 + 2] = kcv[ct] - l4[2];
+            lg[ct][4 * q4 + 3] = kcv[ct] - l4[3];
+        }
+    }
+    gemm_logits<NCT>(lg, xs + c * g.XS, h, Wl4, g);
+
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lg[ct][r] = __builtin_amdgcn_exp2f(lg[ct][r]);
+
+    // GEMM 2: register r of the logits tile holds gamma[frame acc_row(r,h)][comp c] = A operand
+    // of the k-pair {acc_row(r,0), acc_row(r,1)}; B = staged frame row, 32 feature columns per tile.
+    const float *xcol = xs + 4 * h * g.XS + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float *xrow = xcol + acc_row(r, 0) * g.XS;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const float b = xrow[jt * 32];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct][jt] = SKM_MFMA32(lg[ct][r], b, acc[ct][jt]);
+            if (WITH_S) {
+                const float b2 = b * b;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct][NJT * (WITH_S ? 1 : 0) + jt] = SKM_MFMA32(lg[ct][r], b2, acc[ct][NJT * (WITH_S ? 1 : 0) + jt]);
+            }
+        }
+    }
+    wave_lds_fence();  // every read of xs retired (in order) before the next tile is staged
+}
+
+// Fold the f32 accumulators into this wave's private f64 slab (zeroed by the host before the
+// launch; plain read-modify-write, one accumulator tile = 16 loads in flight at a time) and clear them.
+template <int NCT, int NF>
+__device__ __forceinline__ void flush_slab(f32x16 (&acc)[NCT][NF], double *slab_lane)
+{
+    constexpr int NFW = NF * 32;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int jf = 0; jf < NF; ++jf) {
+            double *p = slab_lane + ct * 32 * NFW + jf * 32;
+            double old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = p[acc_row(r, 0) * NFW];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[acc_row(r, 0) * NFW] = old[r] + (double)acc[ct][jf][r];
+                acc[ct][jf][r] = 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+// Baum-Welch flush (one store per session): lane (c,h) owns column jf*32+c of components
+// acc_row(r,h).  Column < D goes to stat1 (component-major, index comp*D + d), column D (the ones
+// column) to stat0.
+template <int NCT, int NF>
+__device__ __forceinline__ void flush_session(f32x16 (&acc)[NCT][NF], double *s0, double *s1, int cb, int C,
+                                              int D, int lane)
+{
+    const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int jf = 0; jf < NF; ++jf) {
+            const int col = jf * 32 + c;
+            const int comp0 = (cb * NCT + ct) * 32 + 4 * h;
+            double *p = (col < D) ? (s1 + (long)comp0 * D + col) : (s0 + comp0);
+            const long stride = (col < D) ? D : 1;
+            const int nlive = (col <= D) ? (C - comp0) : 0;  // rows acc_row(r,0) < nlive are stored
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (acc_row(r, 0) < nlive) p[acc_row(r, 0) * stride] = (double)acc[ct][jf][r];
+                acc[ct][jf][r] = 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+template <int NJT, int NCT, bool WITH_S, bool BW>
+__global__ __launch_bounds__(512, 2) void k_stats(StatsArgs a)
+{
+    constexpr int NF = NJT * (WITH_S ? 2 : 1);
+    constexpr int NFW = NF * 32;
+    extern __shared__ __align__(16) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int cb = blockIdx.x % a.n_cb, fs = blockIdx.x / a.n_cb;
+    const TileGeom g = a.g;
+
+    float *Wl = smem;
+    const int wfloats = NCT * g.NG * 256;
+    float *xs = smem + wfloats + wave * (32 * g.XS + 32);
+    float *ls = xs + 32 * g.XS;
+
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wp) + (long)cb * (wfloats / 4);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(Wl);
+        for (int i = threadIdx.x; i < wfloats / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    init_tile_padding(xs, g, lane);
+    __syncthreads();
+
+    float kcv[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) kcv[ct] = a.kc[(cb * NCT + ct) * 32 + c];
+
+    const f32x4 *Wl4 = reinterpret_cast<const f32x4 *>(Wl) + lane;
+    const long slot = (long)fs * NW + wave, n_slots = (long)a.n_fs * NW;
+
+    f32x16 acc[NCT][NF];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int jf = 0; jf < NF; ++jf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
+
+    if (!BW) {
+        // EM: this wave owns tiles [ta, tb); accumulators are folded into f64 every SKM_FLUSH_TILES.
+        double *slab_lane =
+            a.slabs + ((long)blockIdx.x * NW + wave) * (long)(NCT * 32 * NFW) + (4 * h) * NFW + c;
+        const long tiles = (a.T + 31) >> 5;
+        const long ta = tiles * slot / n_slots, tb = tiles * (slot + 1) / n_slots;
+        for (long base = ta; base < tb; base += SKM_FLUSH_TILES) {
+            const long end = (base + SKM_FLUSH_TILES < tb) ? base + SKM_FLUSH_TILES : tb;
+#pragma unroll 1
+            for (long tile = base; tile < end; ++tile) {
+                const long t0 = tile << 5;
+                const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
+                stats_tile<NJT, NCT, WITH_S>(acc, xs, ls, a.X, a.lse2, t0, nvalid, g, Wl4, kcv, lane);
+            }
+            flush_slab<NCT, NF>(acc, slab_lane);
+        }
+    } else {
+        // Baum-Welch: sessions are dealt round-robin to the wave slots of this component block;
+        // one session = one f32 accumulation, stored as f64 at its end.
+        const int C = a.C, D = g.D;
+#pragma unroll 1
+        for (long s = slot; s < a.S; s += n_slots) {
+            const long b = a.seg_off[s], e = a.seg_off[s + 1];
+#pragma unroll 1
+            for (long t0 = b; t0 < e; t0 += 32) {
+                const int nvalid = (int)((e - t0) < 32 ? (e - t0) : 32);
+                stats_tile<NJT, NCT, WITH_S>(acc, xs, ls, a.X, a.lse2, t0, nvalid, g, Wl4, kcv, lane);
+            }
+            flush_session<NCT, NF>(acc, a.stat0 + s * (long)C, a.stat1 + s * (long)C * D, cb, C, D, lane);
+        }
+    }
+}
+
+// Sum the per-wave f64 slabs in a fixed order into out = [N | F | S | llk].
+__global__ __launch_bounds__(256) void k_reduce_slabs(const double *__restrict__ slabs, int n_cb, int n_fs, int NW,
+                                                      int NCT, int NJT, int NF, int C, int D,
+                                                      double *__restrict__ out, int accumulate,
+                                                      const double *__restrict__ llk_part, int n_llk)
+{
+    const int NFW = NF * 32;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) {
+        double l = 0.0;
+        for (int i = 0; i < n_llk; ++i) l += llk_part[i];
+        double *p = out + C + 2L * C * D;
+        *p = accumulate ? (*p + l) : l;
+    }
+    const int comp = (int)(idx / NFW), col = (int)(idx - (long)comp * NFW);
+    if (comp >= C) return;
+    double *dst;
+    if (col < NJT * 32) {
+        if (col < D)
+            dst = out + C + (long)comp * D + col;
+        else if (col == D)
+            dst = out + comp;
+        else
+            return;
+    } else {
+        const int d = col - NJT * 32;
+        if (d >= D) return;
+        dst = out + C + (long)C * D + (long)comp * D + d;
+    }
+    const int cb = (comp >> 5) / NCT;
+    const int cl = comp - cb * NCT * 32;
+    const long slab_elems = (long)NCT * 32 * NFW;
+    double sum = 0.0;
+    for (int fs = 0; fs < n_fs; ++fs)
+        for (int w = 0; w < NW; ++w) {
+            const long slot = ((long)fs * n_cb + cb) * NW + w;
+            sum += slabs[slot * slab_elems + (long)cl * NFW + col];
+        }
+    *dst = accumulate ? (*dst + sum) : sum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column moments (sum x, sum x^2) -- HBM-bound
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_moments(const float *__restrict__ X, long T, int D, double *__restrict__ part)
+{
+    // each wave owns a contiguous range of rows; lane handles columns lane, lane+64, ...
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wslot = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    const long nslots = (long)gridDim.x * (blockDim.x >> 6);
+    const long ra = T * wslot / nslots, rb = T * (wslot + 1) / nslots;
+    double *dst = part + wslot * 2L * D;
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        double s1 = 0.0, s2 = 0.0;
+        if (d < D) {
+            for (long t = ra; t < rb; ++t) {
+                const double v = (double)X[t * D + d];
+                s1 += v;
+                s2 = fma(v, v, s2);
+            }
+            dst[d] = s1;
+            dst[D + d] = s2;
+        }
+    }
+}
+
+__global__ void k_moments_reduce(const double *__restrict__ part, int nslots, int D, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * D) return;
+    double s = 0.0;
+    for (int k = 0; k < nslots; ++k) s += part[(long)k * 2 * D + i];
+    out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static const double LOG2E = 1.4426950408889634074;
+
+extern "C" size_t skm_gmm_packed_bytes(int C, int D)
+{
+    if (C <= 0 || D <= 0) return 0;
+    const GmmGeom g = skm_geom(C, D);
+    return ((size_t)g.CTpad * g.NCH * 256 + (size_t)g.CTpad * 32) * sizeof(float);
+}
+
+extern "C" int skm_gmm_pack(void *ctx, const double *w, const double *mu, const double *ic, int C, int D,
+                            void *packed_dev, void *stream)
+{
+    SKM_REQUIRE(ctx && w && mu && ic && packed_dev, "skm_gmm_pack: NULL argument");
+    SKM_REQUIRE(C > 0 && D > 0, "skm_gmm_pack: bad shape C=%d D=%d", C, D);
+    const GmmGeom g = skm_geom(C, D);
+    const size_t nW = (size_t)g.CTpad * g.NCH * 256, nK = (size_t)g.CTpad * 32;
+    std::vector<float> img(nW + nK, 0.f);
+    float *wp = img.data(), *kc = img.data() + nW;
+    for (int tile = 0; tile < g.CTpad; ++tile)
+        for (int grp = 0; grp < g.NCH; ++grp)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int comp = tile * 32 + (lane & 31), h = lane >> 5;
+                for (int i = 0; i < 4; ++i) {
+                    int d, kind;
+                    if (grp < 2 * g.NP) {
+                        d = 8 * (grp >> 1) + 4 * h + i;
+                        kind = grp & 1;
+                    } else {
+                        d = 8 * g.NP + i;
+                        kind = h;
+                    }
+                    double v = 0.0;
+                    if (comp < C && d < D) {
+                        const double icv = ic[(size_t)comp * D + d];
+                        v = kind ? (-0.5 * LOG2E * icv) : (LOG2E * mu[(size_t)comp * D + d] * icv);
+                    }
+                    wp[(((size_t)tile * g.NCH + grp) * 64 + lane) * 4 + i] = (float)v;
+                }
+            }
+    const double half_d_log2pi = 0.5 * D * log(2.0 * M_PI);
+    for (int comp = 0; comp < g.CTpad * 32; ++comp) {
+        double v = -1.0e30;
+        if (comp < C) {
+            double logdet_inv = 0.0, quad = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double icv = ic[(size_t)comp * D + d], m = mu[(size_t)comp * D + d];
+                logdet_inv += log(icv);
+                quad += m * m * icv;
+            }
+            v = LOG2E * (log(w[comp]) + 0.5 * logdet_inv - half_d_log2pi - 0.5 * quad);
+            if (!(v > -1.0e30)) v = -1.0e30;  // w = 0 or NaN: component never wins
+        }
+        kc[comp] = (float)v;
+    }
+    SKM_HIP(hipMemcpyAsync(packed_dev, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice,
+                           (hipStream_t)stream));
+    SKM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return SKM_OK;
+}
+
+// Launch plan shared by every entry point.
+struct Plan {
+    GmmGeom g;
+    TileGeom tg;
+    int nct1, nw1, n_cb1, n_fs1;
+    size_t lds1;
+    int nct2, nw2, n_cb2, n_fs2, nf2;
+    size_t lds2;
+    int n_llk;
+    // workspace offsets (bytes)
+    size_t off_pm, off_ps, off_lse, off_llk, off_slabs, total;
+};
+
+static size_t lds_bytes(int nct, int nw, const GmmGeom &g)
+{
+    return ((size_t)nct * g.NCH * 256 + (size_t)nw * (32 * g.XS + 32)) * sizeof(float);
+}
+
+static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan *p)
+{
+    SKM_REQUIRE(T >= 0 && C > 0 && D > 0, "bad shape T=%ld C=%d D=%d", T, C, D);
+    p->g = skm_geom(C, D);
+    const GmmGeom &g = p->g;
+    if (g.NJT > 5) {
+        skm_set_error("feature dimension %d not supported (max 159)", D);
+        return SKM_ERR_UNSUPPORTED;
+    }
+    p->tg.D = D;
+    p->tg.XS = g.XS;
+    p->tg.NG = g.NCH;
+    p->tg.NP = g.NP;
+    p->tg.tail = g.tail;
+    p->tg.vec4 = (D % 4 == 0) ? 1 : 0;
+    // sweep 1: largest component block / wave count that fits the LDS
+    p->nct1 = 0;
+    for (int nw = 8; nw >= 1 && !p->nct1; nw >>= 1)
+        for (int nct = 4; nct >= 1; nct >>= 1)
+            if (lds_bytes(nct, nw, g) <= SKM_LDS_BUDGET) {
+                p->nct1 = nct;
+                p->nw1 = nw;
+                break;
+            }
+    // sweep 2: component tiles per wave limited by the accumulator registers (NCT*NF*16 <= 128..160)
+    p->nf2 = g.NJT * (with_s ? 2 : 1);
+    p->nct2 = (p->nf2 <= 4) ? 2 : 1;
+    p->nw2 = 0;
+    for (int nw = 8; nw >= 1; nw >>= 1)
+        if (lds_bytes(p->nct2, nw, g) <= SKM_LDS_BUDGET) {
+            p->nw2 = nw;
+            break;
+        }
+    if (!p->nct1 || !p->nw2) {
+        skm_set_error("no launch configuration fits the LDS for D=%d", D);
+        return SKM_ERR_UNSUPPORTED;
+    }
+    p->lds1 = lds_bytes(p->nct1, p->nw1, g);
+    p->lds2 = lds_bytes(p->nct2, p->nw2, g);
+    p->n_cb1 = g.CTpad / p->nct1;
+    // padding tiles only matter up to a multiple of the block; blocks that are all padding are skipped
+    p->n_cb1 = (g.CT + p->nct1 - 1) / p->nct1;
+    p->n_cb2 = (g.CT + p->nct2 - 1) / p->nct2;
+    const int wgs = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    p->n_fs1 = wgs / p->n_cb1 > 0 ? wgs / p->n_cb1 : 1;
+    p->n_fs2 = wgs / p->n_cb2 > 0 ? wgs / p->n_cb2 : 1;
+    p->n_llk = 1024;
+    size_t off = 0;
+    p->off_pm = off;
+    off += skm_align_up((size_t)p->n_cb1 * (size_t)T * sizeof(float), 256);
+    p->off_ps = off;
+    off += skm_align_up((size_t)p->n_cb1 * (size_t)T * sizeof(float), 256);
+    p->off_lse = off;
+    off += skm_align_up((size_t)T * sizeof(float), 256);
+    p->off_llk = off;
+    off += skm_align_up((size_t)p->n_llk * sizeof(double), 256);
+    p->off_slabs = off;
+    // slabs sized for the EM (with S) configuration, the largest user
+    {
+        const int nf = g.NJT * 2, nct = (nf <= 4) ? 2 : 1;
+        int nw = 8;
+        while (nw > 1 && lds_bytes(nct, nw, g) > SKM_LDS_BUDGET) nw >>= 1;
+        const int ncb = (g.CT + nct - 1) / nct;
+        const int nfs = wgs / ncb > 0 ? wgs / ncb : 1;
+        off += skm_align_up((size_t)ncb * nfs * nw * nct * 32 * nf * 32 * sizeof(double), 256);
+    }
+    p->total = off;
+    return SKM_OK;
+}
+
+extern "C" size_t skm_gmm_workspace_bytes(void *ctx, long T, int C, int D)
+{
+    if (!ctx) return 0;
+    Plan p;
+    if (make_plan(static_cast<SkmCtx *>(ctx), T, C, D, true, &p) != SKM_OK) return 0;
+    return p.total;
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes)
+{
+    SKM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes));
+    return SKM_OK;
+}
+
+static int launch_lse(const Plan &p, const float *X, long T, const float *wp, const float *kc, char *ws,
+                      float *loglik, hipStream_t st)
+{
+    LseArgs a;
+    a.X = X;
+    a.T = T;
+    a.g = p.tg;
+    a.wp = wp;
+    a.kc = kc;
+    a.pm = reinterpret_cast<float *>(ws + p.off_pm);
+    a.ps = reinterpret_cast<float *>(ws + p.off_ps);
+    a.n_cb = p.n_cb1;
+    a.n_fs = p.n_fs1;
+    const dim3 grid(p.n_cb1 * p.n_fs1), block(64 * p.nw1);
+    int rc = SKM_OK;
+    switch (p.nct1) {
+    case 4:
+        if ((rc = set_lds(k_lse_partial<4>, p.lds1))) return rc;
+        hipLaunchKernelGGL(k_lse_partial<4>, grid, block, p.lds1, st, a);
+        break;
+    case 2:
+        if ((rc = set_lds(k_lse_partial<2>, p.lds1))) return rc;
+        hipLaunchKernelGGL(k_lse_partial<2>, grid, block, p.lds1, st, a);
+        break;
+    default:
+        if ((rc = set_lds(k_lse_partial<1>, p.lds1))) return rc;
+        hipLaunchKernelGGL(k_lse_partial<1>, grid, block, p.lds1, st, a);
+        break;
+    }
+    SKM_HIP(hipGetLastError());
+    long nb = (T + 255) / 256;
+    if (nb > p.n_llk) nb = p.n_llk;
+    if (nb < 1) nb = 1;
+    // unused partial slots must read as zero
+    SKM_HIP(hipMemsetAsync(ws + p.off_llk, 0, p.n_llk * sizeof(double), st));
+    hipLaunchKernelGGL(k_lse_combine, dim3((unsigned)nb), dim3(256), 0, st, a.pm, a.ps, p.n_cb1, T,
+                       reinterpret_cast<float *>(ws + p.off_lse), loglik, reinterpret_cast<double *>(ws + p.off_llk));
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
+template <int NJT, bool WITH_S, bool BW>
+static int launch_stats_t(const Plan &p, const StatsArgs &a, hipStream_t st)
+{
+    constexpr int NF = NJT * (WITH_S ? 2 : 1);
+    constexpr int NCT = (NF <= 4) ? 2 : 1;
+    int rc = set_lds(k_stats<NJT, NCT, WITH_S, BW>, p.lds2);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_stats<NJT, NCT, WITH_S, BW>), dim3(p.n_cb2 * p.n_fs2), dim3(64 * p.nw2), p.lds2, st, a);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
+template <bool WITH_S, bool BW>
+static int launch_stats(const Plan &p, const StatsArgs &a, hipStream_t st)
+{
+    switch (p.g.NJT) {
+    case 1: return launch_stats_t<1, WITH_S, BW>(p, a, st);
+    case 2: return launch_stats_t<2, WITH_S, BW>(p, a, st);
+    case 3: return launch_stats_t<3, WITH_S, BW>(p, a, st);
+    case 4: return launch_stats_t<4, WITH_S, BW>(p, a, st);
+    case 5: return launch_stats_t<5, WITH_S, BW>(p, a, st);
+    }
+    skm_set_error("unsupported NJT=%d", p.g.NJT);
+    return SKM_ERR_UNSUPPORTED;
+}
+
+static int check_common(void *ctx, const float *X, long T, int C, int D, const void *packed, void *ws,
+                        size_t ws_bytes, const Plan &p, const char *who)
+{
+    SKM_REQUIRE(ctx && packed, "%s: NULL ctx/packed", who);
+    SKM_REQUIRE(T == 0 || X != nullptr, "%s: X is NULL", who);
+    SKM_REQUIRE(((uintptr_t)X & 15) == 0, "%s: X must be 16-byte aligned", who);
+    SKM_REQUIRE(((uintptr_t)packed & 15) == 0, "%s: packed image must be 16-byte aligned", who);
+    SKM_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0, "%s: workspace NULL or not 256-byte aligned", who);
+    if (ws_bytes < p.total) {
+        skm_set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, p.total);
+        return SKM_ERR_WORKSPACE;
+    }
+    (void)C;
+    (void)D;
+    return SKM_OK;
+}
+
+extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, const void *packed, double *out,
+                             int accumulate, void *ws_, size_t ws_bytes, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx != nullptr, "skm_gmm_estep: NULL ctx");
+    Plan p;
+    int rc = make_plan(ctx, T, C, D, true, &p);
+    if (rc) return rc;
+    if ((rc = check_common(ctx_, X, T, C, D, packed, ws_, ws_bytes, p, "skm_gmm_estep"))) return rc;
+    SKM_REQUIRE(out != nullptr, "skm_gmm_estep: out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = static_cast<char *>(ws_);
+    const float *wp = static_cast<const float *>(packed);
+    const float *kc = wp + (size_t)p.g.CTpad * p.g.NCH * 256;
+    if ((rc = launch_lse(p, X, T, wp, kc, ws, nullptr, st))) return rc;
+    StatsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = X;
+    a.T = T;
+    a.g = p.tg;
+    a.wp = wp;
+    a.kc = kc;
+    a.lse2 = reinterpret_cast<const float *>(ws + p.off_lse);
+    a.n_cb = p.n_cb2;
+    a.n_fs = p.n_fs2;
+    a.C = C;
+    a.slabs = reinterpret_cast<double *>(ws + p.off_slabs);
+    SKM_HIP(hipMemsetAsync(a.slabs, 0,
+                           (size_t)p.n_cb2 * p.n_fs2 * p.nw2 * p.nct2 * 32 * p.nf2 * 32 * sizeof(double), st));
+    if ((rc = launch_stats<true, false>(p, a, st))) return rc;
+    const long n_out = (long)C * p.nf2 * 32;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, a.slabs, p.n_cb2,
+                       p.n_fs2, p.nw2, p.nct2, p.g.NJT, p.nf2, C, D, out, accumulate,
+                       reinterpret_cast<const double *>(ws + p.off_llk), p.n_llk);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
+extern "C" int skm_gmm_loglik(void *ctx_, const float *X, long T, int C, int D, const void *packed, float *loglik,
+                              void *ws_, size_t ws_bytes, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx != nullptr, "skm_gmm_loglik: NULL ctx");
+    Plan p;
+    int rc = make_plan(ctx, T, C, D, true, &p);
+    if (rc) return rc;
+    if ((rc = check_common(ctx_, X, T, C, D, packed, ws_, ws_bytes, p, "skm_gmm_loglik"))) return rc;
+    SKM_REQUIRE(loglik != nullptr, "skm_gmm_loglik: loglik is NULL");
+    const float *wp = static_cast<const float *>(packed);
+    const float *kc = wp + (size_t)p.g.CTpad * p.g.NCH * 256;
+    return launch_lse(p, X, T, wp, kc, static_cast<char *>(ws_), loglik, (hipStream_t)stream);
+}
+
+extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *seg_off, int S, int C, int D,
+                            const void *packed, double *stat0, double *stat1, void *ws_, size_t ws_bytes,
+                            void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx != nullptr, "skm_bw_stats: NULL ctx");
+    Plan p;
+    int rc = make_plan(ctx, T, C, D, false, &p);
+    if (rc) return rc;
+    if ((rc = check_common(ctx_, X, T, C, D, packed, ws_, ws_bytes, p, "skm_bw_stats"))) return rc;
+    SKM_REQUIRE(S >= 0 && (S == 0 || (seg_off && stat0 && stat1)), "skm_bw_stats: NULL output or offsets");
+    if (S == 0) return SKM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = static_cast<char *>(ws_);
+    const float *wp = static_cast<const float *>(packed);
+    const float *kc = wp + (size_t)p.g.CTpad * p.g.NCH * 256;
+    if ((rc = launch_lse(p, X, T, wp, kc, ws, nullptr, st))) return rc;
+    StatsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = X;
+    a.T = T;
+    a.g = p.tg;
+    a.wp = wp;
+    a.kc = kc;
+    a.lse2 = reinterpret_cast<const float *>(ws + p.off_lse);
+    a.n_cb = p.n_cb2;
+    a.n_fs = p.n_fs2;
+    a.C = C;
+    a.seg_off = seg_off;
+    a.S = S;
+    a.stat0 = stat0;
+    a.stat1 = stat1;
+    return launch_stats<false, true>(p, a, st);
+}
+
+extern "C" size_t skm_moments_workspace_bytes(void *ctx_, int D)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    if (!ctx || D <= 0) return 0;
+    const size_t nslots = (size_t)ctx->cu_count * 4 * 4;
+    return skm_align_up(nslots * 2 * (size_t)D * sizeof(double), 256);
+}
+
+extern "C" int skm_moments(void *ctx_, const float *X, long T, int D, double *out, void *ws, size_t ws_bytes,
+                           void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && out && ws && (T == 0 || X), "skm_moments: NULL argument");
+    SKM_REQUIRE(D > 0 && T >= 0, "skm_moments: bad shape");
+    if (ws_bytes < skm_moments_workspace_bytes(ctx_, D)) {
+        skm_set_error("skm_moments: workspace too small");
+        return SKM_ERR_WORKSPACE;
+    }
+    const int blocks = ctx->cu_count * 4, nslots = blocks * 4;
+    hipStream_t st = (hipStream_t)stream;
+    SKM_HIP(hipMemsetAsync(ws, 0, (size_t)nslots * 2 * D * sizeof(double), st));
+    hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(256), 0, st, X, T, D, static_cast<double *>(ws));
+    SKM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_moments_reduce, dim3((2 * D + 127) / 128), dim3(128), 0, st,
+                       static_cast<const double *>(ws), nslots, D, out);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}

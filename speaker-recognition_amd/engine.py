@@ -1,0 +1,244 @@
+"""ctypes binding of libskm.so (include/skm.h) + the device-side plumbing of the hot path.
+
+PyTorch is used for device memory, streams and torch.distributed only; every number on the
+path is produced by the hand-written gfx950 kernels in csrc/.  There is NO CPU fallback: if
+the library or a GPU is missing, constructing a :class:`HipEngine` raises.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libskm.so")
+
+_c_void_p = ctypes.c_void_p
+_c_size_t = ctypes.c_size_t
+_c_int = ctypes.c_int
+_c_long = ctypes.c_long
+_dp = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); exactly the declarations of include/skm.h
+SIGNATURES = {
+    "skm_version": (_c_int, []),
+    "skm_last_error": (ctypes.c_char_p, []),
+    "skm_ctx_create": (_c_int, [_c_int, ctypes.POINTER(_c_void_p)]),
+    "skm_ctx_destroy": (_c_int, [_c_void_p]),
+    "skm_ctx_cu_count": (_c_int, [_c_void_p]),
+    "skm_gmm_packed_bytes": (_c_size_t, [_c_int, _c_int]),
+    "skm_gmm_pack": (_c_int, [_c_void_p, _dp, _dp, _dp, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "skm_gmm_workspace_bytes": (_c_size_t, [_c_void_p, _c_long, _c_int, _c_int]),
+    "skm_gmm_estep": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
+                               _c_void_p, _c_size_t, _c_void_p]),
+    "skm_gmm_loglik": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p,
+                                _c_void_p, _c_size_t, _c_void_p]),
+    "skm_bw_stats": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
+                              _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "skm_moments_workspace_bytes": (_c_size_t, [_c_void_p, _c_int]),
+    "skm_moments": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class SkmError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libskm.so and attach the prototypes.  Raises if the library is not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise SkmError("libskm.so not found at %s -- build it with speaker-recognition_amd/csrc/build.sh "
+                           "(there is no CPU fallback)" % p)
+        lib = ctypes.CDLL(p)
+        for name, (res, args) in SIGNATURES.items():
+            if name.startswith("skm_tv") and not hasattr(lib, name):
+                continue
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def _as_f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class HipEngine(object):
+    """One engine per GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise SkmError("no GPU visible: the sidekit hot path runs on MI355X only (no CPU fallback)")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        ctx = _c_void_p()
+        self._check(self.lib.skm_ctx_create(self.device_index, ctypes.byref(ctx)))
+        self.ctx = ctx
+        self._ws = None
+        self._ws_bytes = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.skm_ctx_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc):
+        if rc != 0:
+            raise SkmError("libskm error %d: %s" % (rc, self.lib.skm_last_error().decode("utf-8", "replace")))
+
+    def _stream(self):
+        return _c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, nbytes):
+        if nbytes > self._ws_bytes:
+            self._ws = None
+            self._ws = self.torch.empty(int(nbytes) + 256, dtype=self.torch.uint8, device=self.device)
+            self._ws_bytes = int(nbytes)
+        base = self._ws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        return aligned
+
+    def cu_count(self):
+        return self.lib.skm_ctx_cu_count(self.ctx)
+
+    def upload_frames(self, x):
+        """host (T x D) array -> float32 device tensor (the kernels' input layout)."""
+        torch = self.torch
+        if isinstance(x, torch.Tensor):
+            t = x.to(device=self.device, dtype=torch.float32)
+        else:
+            a = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+            if a.ndim == 1:
+                a = a[:, None]
+            t = torch.from_numpy(a).to(self.device)
+        return t.contiguous()
+
+    # ------------------------------------------------------------------ GMM
+    def pack(self, w, mu, invcov):
+        torch = self.torch
+        w = _as_f64(w)
+        mu = _as_f64(mu)
+        invcov = _as_f64(invcov)
+        C, D = mu.shape
+        assert w.shape == (C,) and invcov.shape == (C, D)
+        nbytes = self.lib.skm_gmm_packed_bytes(C, D)
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._check(self.lib.skm_gmm_pack(self.ctx, w.ctypes.data_as(_dp), mu.ctypes.data_as(_dp),
+                                          invcov.ctypes.data_as(_dp), C, D, _c_void_p(packed.data_ptr()),
+                                          self._stream()))
+        return PackedGMM(packed, C, D)
+
+    def estep(self, X, gmm, out=None, accumulate=False):
+        """[N | F | S | llk] float64 device tensor for the frames X (T x D float32 device tensor)."""
+        torch = self.torch
+        T, D = X.shape
+        assert D == gmm.D and X.dtype == torch.float32 and X.is_contiguous()
+        C = gmm.C
+        n = 2 * C * D + C + 1
+        if out is None:
+            out = torch.empty(n, dtype=torch.float64, device=self.device)
+            accumulate = False
+        assert out.numel() == n and out.dtype == torch.float64
+        need = self.lib.skm_gmm_workspace_bytes(self.ctx, T, C, D)
+        ws = self.workspace(need)
+        self._check(self.lib.skm_gmm_estep(self.ctx, _c_void_p(X.data_ptr()), T, C, D,
+                                           _c_void_p(gmm.packed.data_ptr()), _c_void_p(out.data_ptr()),
+                                           1 if accumulate else 0, _c_void_p(ws), need, self._stream()))
+        return out
+
+    def loglik(self, X, gmm):
+        torch = self.torch
+        T, D = X.shape
+        assert D == gmm.D
+        out = torch.empty(T, dtype=torch.float32, device=self.device)
+        need = self.lib.skm_gmm_workspace_bytes(self.ctx, T, gmm.C, D)
+        ws = self.workspace(need)
+        self._check(self.lib.skm_gmm_loglik(self.ctx, _c_void_p(X.data_ptr()), T, gmm.C, D,
+                                            _c_void_p(gmm.packed.data_ptr()), _c_void_p(out.data_ptr()),
+                                            _c_void_p(ws), need, self._stream()))
+        return out
+
+    def bw_stats(self, X, seg_off, gmm, stat0=None, stat1=None):
+        """Per-session N (S x C) and F (S x C*D, component-major), float64 device tensors."""
+        torch = self.torch
+        T, D = X.shape
+        assert D == gmm.D and X.dtype == torch.float32 and X.is_contiguous()
+        if not isinstance(seg_off, torch.Tensor):
+            seg_off = torch.as_tensor(np.asarray(seg_off, dtype=np.int64))
+        seg_off = seg_off.to(device=self.device, dtype=torch.int64).contiguous()
+        S = seg_off.numel() - 1
+        C = gmm.C
+        if stat0 is None:
+            stat0 = torch.empty((S, C), dtype=torch.float64, device=self.device)
+        if stat1 is None:
+            stat1 = torch.empty((S, C * D), dtype=torch.float64, device=self.device)
+        assert stat0.shape == (S, C) and stat1.shape == (S, C * D)
+        assert stat0.is_contiguous() and stat1.is_contiguous()
+        need = self.lib.skm_gmm_workspace_bytes(self.ctx, T, C, D)
+        ws = self.workspace(need)
+        self._check(self.lib.skm_bw_stats(self.ctx, _c_void_p(X.data_ptr()), T, _c_void_p(seg_off.data_ptr()), S,
+                                          C, D, _c_void_p(gmm.packed.data_ptr()), _c_void_p(stat0.data_ptr()),
+                                          _c_void_p(stat1.data_ptr()), _c_void_p(ws), need, self._stream()))
+        return stat0, stat1
+
+    def moments(self, X):
+        """[sum x | sum x^2] over the rows of X, float64 device tensor of 2*D."""
+        torch = self.torch
+        T, D = X.shape
+        out = torch.empty(2 * D, dtype=torch.float64, device=self.device)
+        need = self.lib.skm_moments_workspace_bytes(self.ctx, D)
+        ws = self.workspace(need)
+        self._check(self.lib.skm_moments(self.ctx, _c_void_p(X.data_ptr()), T, D, _c_void_p(out.data_ptr()),
+                                         _c_void_p(ws), need, self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ host conveniences
+    def to_host(self, t):
+        return t.detach().cpu().numpy()
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+class PackedGMM(object):
+    """Device image of a diagonal GMM in MFMA fragment order (see csrc/skm_gmm.hip)."""
+
+    def __init__(self, packed, C, D):
+        self.packed = packed
+        self.C = C
+        self.D = D
+
+
+_default_engine = None
+
+
+def default_engine():
+    """The process-wide engine on the current CUDA/HIP device (LOCAL_RANK aware)."""
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = HipEngine()
+    return _default_engine
+
+
+def set_default_engine(engine):
+    global _default_engine
+    _default_engine = engine

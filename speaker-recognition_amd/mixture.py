@@ -1,0 +1,392 @@
+"""Mixture: diagonal-covariance GMM with the method surface of sidekit.Mixture
+(reference: sidekit/mixture.py), E-step on MI355X.
+
+What runs where
+  * E-step (`_expectation`, `_expectation_list`, and therefore `EM_split` / `EM_uniform`):
+    hand-written gfx950 kernels through libskm (csrc/skm_gmm.hip); frames live in HBM as float32
+    for the whole training run instead of being re-read from disk every iteration
+    (mixture.py:586-588).
+  * M-step, variance control, split, `_compute_all`: float64 NumPy on the host.  They are C x D
+    element-wise updates on already-reduced statistics and the split takes a
+    discrete arg-max that must be bit-robust, so they stay in float64; on a multi-GPU job every
+    rank runs them identically on the all-reduced statistics (no broadcast, replaces
+    sidekit_mpi.py:401,514).
+  * Multi-GPU: one process per GPU; frames are cut like numpy.array_split over ranks
+    (sidekit_mpi.py:408-410) unless the features server says it is already sharded; the packed
+    [N | F | S | llk] float64 buffer is summed with ONE all-reduce (RCCL) per iteration.
+
+Only the diagonal-covariance path exists (north star); full-covariance branches of the
+reference (mixture.py:441-459, 563-565, 604-610, 826-909) are out of scope.
+"""
+import copy
+import logging
+import os
+
+import numpy as np
+
+from . import dist
+from . import engine as _engine
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Mixture(object):
+    """Gaussian mixture model storage + EM training (sidekit/mixture.py:67-197)."""
+
+    def __init__(self, mixture_file_name='', name='empty', engine=None):
+        self.w = np.array([])
+        self.mu = np.array([])
+        self.invcov = np.array([])
+        self.invchol = np.array([])
+        self.cov_var_ctl = np.array([])
+        self.cst = np.array([])
+        self.det = np.array([])
+        self.name = name
+        self.A = 0
+        self._engine = engine
+        if mixture_file_name != '':
+            self.read(mixture_file_name)
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = _engine.default_engine()
+        return self._engine
+
+    def __deepcopy__(self, memo):
+        new = Mixture.__new__(Mixture)
+        for k, v in self.__dict__.items():
+            setattr(new, k, v if k == "_engine" else copy.deepcopy(v, memo))
+        return new
+
+    def __add__(self, other):
+        """Weights, means and inverse covariances are added (mixture.py:203-212)."""
+        new_mixture = Mixture(engine=self._engine)
+        new_mixture.w = self.w + other.w
+        new_mixture.mu = self.mu + other.mu
+        new_mixture.invcov = self.invcov + other.invcov
+        return new_mixture
+
+    def _serialize(self):
+        """Shared-memory serialisation of the reference (mixture.py:236-271) is not needed: the
+        accumulators live in HBM and are combined by all-reduce."""
+        return None
+
+    def get_distrib_nb(self):
+        return self.w.shape[0]
+
+    def distrib_nb(self):
+        return self.w.shape[0]
+
+    def dim(self):
+        return self.mu.shape[1]
+
+    def sv_size(self):
+        return self.mu.shape[1] * self.w.shape[0]
+
+    def get_mean_super_vector(self):
+        return self.mu.flatten()
+
+    def get_invcov_super_vector(self):
+        assert self.invcov.ndim == 2, 'Must be diagonal co-variance.'
+        return self.invcov.flatten()
+
+    def validate(self):
+        """Shape consistency (mixture.py:398-422), diagonal case."""
+        ok = (self.w.ndim == 1)
+        ok &= (self.det.ndim == 1)
+        ok &= (self.cst.ndim == 1)
+        ok &= (self.mu.ndim == 2)
+        ok &= (self.invcov.ndim == 2)
+        if not ok:
+            return False
+        ok &= (self.w.shape[0] == self.mu.shape[0])
+        ok &= (self.w.shape[0] == self.cst.shape[0])
+        ok &= (self.w.shape[0] == self.det.shape[0])
+        ok &= (self.invcov.shape == self.mu.shape)
+        return bool(ok)
+
+    # ------------------------------------------------------------------ I/O (npz; HDF5 when h5py exists)
+    _FIELDS = ("w", "mu", "invcov", "invchol", "cov_var_ctl", "cst", "det")
+
+    def write(self, mixture_file_name, prefix='', mode='w'):
+        """Same dataset names as mixture.py:325-359.  `.h5` needs h5py, anything else is an .npz."""
+        d = os.path.dirname(mixture_file_name)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        data = {prefix + k: np.asarray(getattr(self, k), dtype="d") for k in self._FIELDS}
+        data[prefix + "a"] = np.asarray(self.A, dtype="d")
+        if mixture_file_name.endswith((".h5", ".hdf5")):
+            import h5py  # raises if the GPU box has no h5py: use .npz there
+            with h5py.File(mixture_file_name, mode) as f:
+                for k, v in data.items():
+                    f.create_dataset(k, v.shape, "d", v, compression="gzip", fletcher32=True)
+        else:
+            with open(mixture_file_name, "wb") as f:
+                np.savez(f, **data)
+
+    def read(self, mixture_file_name, prefix=''):
+        if mixture_file_name.endswith((".h5", ".hdf5")):
+            import h5py
+            with h5py.File(mixture_file_name, 'r') as f:
+                get = lambda k: np.asarray(f[prefix + k][()])
+                vals = {k: get(k) for k in self._FIELDS + ("a",)}
+        else:
+            z = np.load(mixture_file_name, allow_pickle=False)
+            vals = {k: z[prefix + k] for k in self._FIELDS + ("a",)}
+        for k in self._FIELDS:
+            setattr(self, k, vals[k])
+        self.w = self.w.reshape(-1)
+        self.A = vals["a"]
+
+    # ------------------------------------------------------------------ parameters
+    def _compute_all(self):
+        """det, cst, A (mixture.py:382-396)."""
+        assert self.invcov.ndim == 2, "only diagonal covariance is supported on this path"
+        self.det = 1.0 / np.prod(self.invcov, axis=1)
+        self.cst = 1.0 / (np.sqrt(self.det) * (2.0 * np.pi) ** (self.dim() / 2.0))
+        self.A = (np.square(self.mu) * self.invcov).sum(1) - 2.0 * (np.log(self.w) + np.log(self.cst))
+
+    def _reset(self):
+        """All values to zero (mixture.py:508-515)."""
+        self.cst.fill(0.0)
+        self.det.fill(0.0)
+        self.w.fill(0.0)
+        self.mu.fill(0.0)
+        self.invcov.fill(0.0)
+        self.A = 0.0
+
+    @staticmethod
+    def variance_control(cov, flooring, ceiling, cov_ctl):
+        """Inclusive floor / ceiling (mixture.py:489-506); modifies and returns `cov`."""
+        floor = flooring * cov_ctl
+        ceil = ceiling * cov_ctl
+        to_floor = np.less_equal(cov, floor)
+        to_ceil = np.greater_equal(cov, ceil)
+        cov[to_floor] = floor[to_floor]
+        cov[to_ceil] = ceil[to_ceil]
+        return cov
+
+    def _split_ditribution(self):
+        """Each Gaussian becomes two, shifted by +-sigma along its largest-variance axis
+        (mixture.py:517-535; the reference's spelling of the name is kept)."""
+        sigma = 1.0 / self.invcov
+        sig_max = np.max(sigma, axis=1)
+        arg_max = np.argmax(sigma, axis=1)
+        shift = np.zeros(self.mu.shape)
+        shift[np.arange(arg_max.shape[0]), arg_max] = np.sqrt(sig_max)
+        self.mu = np.vstack((self.mu - shift, self.mu + shift))
+        self.invcov = np.vstack((self.invcov, self.invcov))
+        self.w = np.concatenate([self.w, self.w]) * 0.5
+        self.cst = np.zeros(self.w.shape)
+        self.det = np.zeros(self.w.shape)
+        self.cov_var_ctl = np.vstack((self.cov_var_ctl, self.cov_var_ctl))
+        self._compute_all()
+
+    def _maximization(self, accum, ceil_cov=10, floor_cov=1e-2):
+        """M-step from the statistics in `accum` (mixture.py:590-611)."""
+        self.w = accum.w / np.sum(accum.w)
+        self.mu = accum.mu / accum.w[:, np.newaxis]
+        cov = accum.invcov / accum.w[:, np.newaxis] - np.square(self.mu)
+        cov = Mixture.variance_control(cov, floor_cov, ceil_cov, self.cov_var_ctl)
+        self.invcov = 1.0 / cov
+        self._compute_all()
+
+    # ------------------------------------------------------------------ E-step on the GPU
+    def _pack(self):
+        return self.engine.pack(self.w, self.mu, self.invcov)
+
+    def _device_frames(self, cep):
+        """float32 device view of `cep` (uploads a host array; device tensors pass through)."""
+        return self.engine.upload_frames(cep)
+
+    def _estep_device(self, X_dev, packed=None):
+        """[N | F | S | llk] of the frames resident in HBM, as a float64 device tensor."""
+        if packed is None:
+            packed = self._pack()
+        return self.engine.estep(X_dev, packed)
+
+    def _unpack_stats(self, flat):
+        C, D = self.distrib_nb(), self.dim()
+        flat = np.asarray(flat, dtype=np.float64)
+        N = flat[:C]
+        F = flat[C:C + C * D].reshape(C, D)
+        S = flat[C + C * D:C + 2 * C * D].reshape(C, D)
+        return N, F, S, float(flat[-1])
+
+    def _expectation(self, accum, cep):
+        """E-step over one block of frames; statistics are ADDED to `accum`; returns the summed
+        log-likelihood (mixture.py:537-568)."""
+        if not _is_torch(cep) and np.asarray(cep).ndim == 1:
+            cep = np.asarray(cep)[:, np.newaxis]
+        X = self._device_frames(cep)
+        flat = self.engine.to_host(self._estep_device(X))
+        N, F, S, llk = self._unpack_stats(flat)
+        accum.w += N
+        accum.mu += F
+        accum.invcov += S
+        return llk
+
+    def _expectation_list(self, stat_acc, feature_list, feature_server, llk_acc=np.zeros(1), num_thread=1):
+        """E-step over a list of feature files (mixture.py:570-588).  `num_thread` is accepted for
+        compatibility and ignored: the parallelism is the GPU's, and the reference's multi-process
+        version is racy.  One device accumulation over all files, one
+        device->host copy."""
+        stat_acc._reset()
+        feature_server.keep_all_features = False
+        packed = self._pack()
+        out = None
+        for feat in feature_list:
+            X = self._device_frames(feature_server.load(feat)[0])
+            out = self.engine.estep(X, packed, out=out, accumulate=out is not None)
+        if out is None:
+            return
+        N, F, S, llk = self._unpack_stats(self.engine.to_host(out))
+        stat_acc.w += N
+        stat_acc.mu += F
+        stat_acc.invcov += S
+        llk_acc[0] += llk
+
+    # ------------------------------------------------------------------ training drivers
+    def _resident_frames(self, features_server, feature_list):
+        """All training frames of THIS rank as one float32 tensor in HBM."""
+        feats = features_server.stack_features_parallel(feature_list, num_thread=1)
+        if dist.is_dist() and not getattr(features_server, "is_sharded", False):
+            a, b = dist.shard_bounds(feats.shape[0])
+            feats = feats[a:b]
+        return self._device_frames(feats)
+
+    def _global_stats(self, X_dev):
+        """E-step on the local shard + all-reduce -> host (N, F, S, llk)."""
+        out = self._estep_device(X_dev)
+        dist.allreduce_sum_(out)
+        return self._unpack_stats(self.engine.to_host(out))
+
+    def _init(self, features_server, feature_list, num_thread=1, X_dev=None):
+        """Single Gaussian whose 'covariance' is the raw second moment E[x^2] -- a quirk of the
+        reference that is kept (mixture.py:613-641)."""
+        if X_dev is None:
+            X_dev = self._resident_frames(features_server, feature_list)
+        mom = self.engine.moments(X_dev)
+        mom = self.engine.torch.cat([mom, self.engine.torch.tensor([float(X_dev.shape[0])], dtype=mom.dtype,
+                                                                   device=mom.device)])
+        dist.allreduce_sum_(mom)
+        mom = self.engine.to_host(mom)
+        D = X_dev.shape[1]
+        n_frames = mom[-1]
+        mu = mom[:D] / n_frames
+        cov = mom[D:2 * D] / n_frames
+        self.mu = mu[None]
+        self.invcov = 1. / cov[None]
+        self.w = np.asarray([1.0])
+        self.cst = np.zeros(self.w.shape)
+        self.det = np.zeros(self.w.shape)
+        self.cov_var_ctl = 1.0 / copy.deepcopy(self.invcov)
+        self._compute_all()
+        return X_dev
+
+    def EM_split(self,
+                 features_server,
+                 feature_list,
+                 distrib_nb,
+                 iterations=(1, 2, 2, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8),
+                 num_thread=1,
+                 llk_gain=0.01,
+                 save_partial=False,
+                 output_file_name="ubm",
+                 ceil_cov=10,
+                 floor_cov=1e-2):
+        """Binary-split EM (mixture.py:643-733).  Returns the per-iteration mean log-likelihoods.
+
+        `num_thread` and `llk_gain` are accepted and unused, as in the reference (its gain test is
+        commented out, mixture.py:711-731)."""
+        llk = []
+        X_dev = self._init(features_server, feature_list, num_thread)
+
+        for it in iterations[:int(np.log2(distrib_nb))]:
+            if save_partial:
+                ext = ".h5" if _has_h5py() else ".npz"
+                self.write('{}_{}g{}'.format(output_file_name, self.get_distrib_nb(), ext), prefix='')
+            self._split_ditribution()
+            accum = copy.deepcopy(self)
+            for i in range(it):
+                accum._reset()
+                N, F, S, l = self._global_stats(X_dev)
+                accum.w += N
+                accum.mu += F
+                accum.invcov += S
+                llk.append(l / np.sum(accum.w))
+                self._maximization(accum, ceil_cov=ceil_cov, floor_cov=floor_cov)
+        return llk
+
+    def EM_uniform(self, cep, distrib_nb, iteration_min=3, iteration_max=10, llk_gain=0.01, do_init=True):
+        """EM from a uniform-slice start with an early stop on the gain (mixture.py:735-794)."""
+        llk = []
+        n_total = cep.shape[0]
+        if do_init:
+            self._init_uniform(cep, distrib_nb)
+        accum = copy.deepcopy(self)
+        local = cep
+        if dist.is_dist():
+            a, b = dist.shard_bounds(n_total)
+            local = cep[a:b]
+        X_dev = self._device_frames(local)
+        for i in range(0, iteration_max):
+            accum._reset()
+            N, F, S, l = self._global_stats(X_dev)
+            accum.w += N
+            accum.mu += F
+            accum.invcov += S
+            llk.append(l / n_total)
+            self._maximization(accum)
+            if i > 0:
+                gain = llk[-1] - llk[-2]
+                if gain < llk_gain and i >= iteration_min:
+                    logging.debug('EM (break) distrib_nb: %d %i/%d gain: %f -- %s, %d',
+                                  self.mu.shape[0], i + 1, iteration_max, gain, self.name, n_total)
+                    break
+        return llk
+
+    def _init_uniform(self, cep, distrib_nb):
+        """Start of EM_uniform with the reference's quirks kept (mixture.py:796-824): every slice
+        ends at the last frame, rows after the first store the covariance (not its inverse) in
+        `invcov`, and `mu` is 1-D when distrib_nb == 1.  One pass over <= distrib_nb suffixes of the
+        data; done on the host in float64 (initialisation, not on the iterated path)."""
+        if _is_torch(cep):
+            cep = cep.detach().cpu().numpy()
+        cep = np.asarray(cep, dtype=np.float64)
+        nb = cep.shape[0]
+        self.w = np.full(distrib_nb, 1.0 / distrib_nb, "d")
+        self.cst = np.zeros(distrib_nb, "d")
+        self.det = np.zeros(distrib_nb, "d")
+        for i in range(0, distrib_nb):
+            start = nb // distrib_nb * i
+            end = max(start + 10, nb)
+            mean = np.mean(cep[start:end, :], axis=0)
+            cov = (cep[start:end, :] ** 2).mean(0)
+            if i == 0:
+                self.mu = mean
+                self.invcov = 1. / cov[None]
+            else:
+                self.mu = np.vstack((self.mu, mean))
+                self.invcov = np.vstack((self.invcov, cov))
+        self.cov_var_ctl = 1.0 / copy.deepcopy(self.invcov)
+        self._compute_all()
+
+    # ------------------------------------------------------------------ scoring helper
+    def log_likelihood(self, cep):
+        """Per-frame log sum_c w_c N(x_t) on the GPU: the `log_lk` of sum_log_probabilities
+        (statserver.py:83-95) without materialising the T x C matrix."""
+        X = self._device_frames(cep)
+        return self.engine.to_host(self.engine.loglik(X, self._pack())).astype(np.float64)
+
+
+def _has_h5py():
+    try:
+        import h5py  # noqa: F401
+        return True
+    except ImportError:
+        return False

@@ -1,0 +1,273 @@
+"""StatServer: container of per-session zero / first order statistics with the method surface of
+sidekit.StatServer that the hot path uses (reference: sidekit/statserver.py:207-326, 377-476,
+609-697, 732-745).
+
+`accumulate_stat` runs on MI355X: the sessions of a batch are concatenated into one float32
+frame matrix in HBM with an offset table, and libskm's Baum-Welch kernel (csrc/skm_gmm.hip,
+k_stats in session mode) writes each session's N (C) and F (C*D, component-major) rows in float64.
+Back-end algebra of the reference class (LDA / WCCN / NAP / PLDA, statserver.py:800-1820) is out
+of scope of this path.
+"""
+import copy
+import logging
+import os
+
+import numpy as np
+
+from . import dist
+from . import engine as _engine
+from .idmap import IdMap
+from .mixture import Mixture
+
+STAT_TYPE = np.float64
+
+
+def sum_log_probabilities(lp):
+    """Kept for API parity (statserver.py:83-95); tiny host helper, not used by the GPU path."""
+    pp_max = np.max(lp, axis=1)
+    log_lk = pp_max + np.log(np.sum(np.exp((lp.transpose() - pp_max).transpose()), axis=1))
+    ind = ~np.isfinite(pp_max)
+    if sum(ind) != 0:
+        log_lk[ind] = pp_max[ind]
+    pp = np.exp((lp.transpose() - log_lk).transpose())
+    return pp, log_lk
+
+
+class StatServer(object):
+    def __init__(self, statserver_file_name=None, distrib_nb=0, feature_size=0, index=None, ubm=None,
+                 engine=None):
+        """Empty, shaped like an IdMap, or read from a file (statserver.py:207-294)."""
+        self.modelset = np.empty(0, dtype="|O")
+        self.segset = np.empty(0, dtype="|O")
+        self.start = np.empty(0, dtype="|O")
+        self.stop = np.empty(0, dtype="|O")
+        self.stat0 = np.array([], dtype=STAT_TYPE)
+        self.stat1 = np.array([], dtype=STAT_TYPE)
+        self._engine = engine
+
+        if ubm is not None:
+            distrib_nb = ubm.w.shape[0]
+            feature_size = ubm.mu.shape[1]
+
+        if statserver_file_name is None:
+            pass
+        elif isinstance(statserver_file_name, IdMap) or _looks_like_idmap(statserver_file_name):
+            self.modelset = statserver_file_name.leftids
+            self.segset = statserver_file_name.rightids
+            self.start = statserver_file_name.start
+            self.stop = statserver_file_name.stop
+            self.stat0 = np.empty((self.segset.shape[0], distrib_nb), dtype=STAT_TYPE)
+            self.stat1 = np.empty((self.segset.shape[0], distrib_nb * feature_size), dtype=STAT_TYPE)
+        elif isinstance(statserver_file_name, str):
+            tmp = StatServer.read(statserver_file_name) if index is None \
+                else StatServer.read_subset(statserver_file_name, index)
+            self.modelset = tmp.modelset
+            self.segset = tmp.segset
+            self.start = tmp.start
+            self.stop = tmp.stop
+            self.stat0 = tmp.stat0.astype(STAT_TYPE)
+            self.stat1 = tmp.stat1.astype(STAT_TYPE)
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = _engine.default_engine()
+        return self._engine
+
+    def __deepcopy__(self, memo):
+        new = StatServer.__new__(StatServer)
+        for k, v in self.__dict__.items():
+            setattr(new, k, v if k == "_engine" else copy.deepcopy(v, memo))
+        return new
+
+    def __repr__(self):
+        ch = '-' * 30 + '\n'
+        ch += 'modelset: ' + self.modelset.__repr__() + '\n'
+        ch += 'segset: ' + self.segset.__repr__() + '\n'
+        ch += 'seg start:' + self.start.__repr__() + '\n'
+        ch += 'seg stop:' + self.stop.__repr__() + '\n'
+        ch += 'stat0:' + self.stat0.__repr__() + '\n'
+        ch += 'stat1:' + self.stat1.__repr__() + '\n'
+        ch += '-' * 30 + '\n'
+        return ch
+
+    def validate(self, warn=False):
+        """statserver.py:308-326."""
+        ok = self.modelset.ndim == 1 \
+            and (self.modelset.shape == self.segset.shape == self.start.shape == self.stop.shape) \
+            and (self.stat0.shape[0] == self.stat1.shape[0] == self.modelset.shape[0]) \
+            and (not bool(self.stat1.shape[1] % self.stat0.shape[1]))
+        if warn and (self.segset.shape != np.unique(self.segset).shape):
+            logging.warning('Duplicated segments in StatServer')
+        return bool(ok)
+
+    # ------------------------------------------------------------------ I/O
+    # Same dataset names and the same float32 storage of stat0/stat1 as statserver.py:431-455: the
+    # float32 rounding is part of the TV input contract.  `.h5` needs h5py; otherwise .npz.
+    def write(self, output_file_name, prefix='', mode='w'):
+        assert self.validate(), "Error: wrong StatServer format"
+        d = os.path.dirname(output_file_name)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        start = np.array([-1 if (v is None or (isinstance(v, float) and np.isnan(v))) else int(v)
+                          for v in self.start], dtype=np.int64)
+        stop = np.array([-1 if (v is None or (isinstance(v, float) and np.isnan(v))) else int(v)
+                         for v in self.stop], dtype=np.int64)
+        data = {prefix + "modelset": np.asarray(self.modelset).astype('S'),
+                prefix + "segset": np.asarray(self.segset).astype('S'),
+                prefix + "stat0": self.stat0.astype(np.float32),
+                prefix + "stat1": self.stat1.astype(np.float32),
+                prefix + "start": start, prefix + "stop": stop}
+        if output_file_name.endswith((".h5", ".hdf5")):
+            import h5py
+            with h5py.File(output_file_name, mode) as f:
+                for k, v in data.items():
+                    f.create_dataset(k, data=v, maxshape=(None,) + v.shape[1:], compression="gzip",
+                                     fletcher32=True)
+        else:
+            with open(output_file_name, "wb") as f:
+                np.savez(f, **data)
+
+    @staticmethod
+    def _load_arrays(statserver_file_name, prefix=''):
+        keys = ("modelset", "segset", "start", "stop", "stat0", "stat1")
+        if statserver_file_name.endswith((".h5", ".hdf5")):
+            import h5py
+            with h5py.File(statserver_file_name, "r") as f:
+                return {k: np.asarray(f[prefix + k][()]) for k in keys}
+        z = np.load(statserver_file_name, allow_pickle=False)
+        return {k: z[prefix + k] for k in keys}
+
+    @staticmethod
+    def read(statserver_file_name, prefix=''):
+        a = StatServer._load_arrays(statserver_file_name, prefix)
+        ss = StatServer()
+        ss.modelset = a["modelset"].astype('U', copy=False)
+        ss.segset = a["segset"].astype('U', copy=False)
+        ss.start = np.empty(a["start"].shape, '|O')
+        ss.stop = np.empty(a["stop"].shape, '|O')
+        ss.start[a["start"] != -1] = a["start"][a["start"] != -1]
+        ss.stop[a["stop"] != -1] = a["stop"][a["stop"] != -1]
+        ss.stat0 = a["stat0"].astype(dtype=STAT_TYPE)
+        ss.stat1 = a["stat1"].astype(dtype=STAT_TYPE)
+        assert ss.validate(), "Error: wrong StatServer format"
+        return ss
+
+    @staticmethod
+    def read_subset(statserver_filename, index, prefix=''):
+        full = StatServer.read(statserver_filename, prefix)
+        if isinstance(index, IdMap) or _looks_like_idmap(index):
+            keep = np.array([np.argwhere(full.segset == s)[0][0] for s in index.rightids])
+        else:
+            keep = np.asarray(index)
+        ss = StatServer()
+        ss.modelset, ss.segset = full.modelset[keep], full.segset[keep]
+        ss.start, ss.stop = full.start[keep], full.stop[keep]
+        ss.stat0, ss.stat1 = full.stat0[keep, :], full.stat1[keep, :]
+        return ss
+
+    # ------------------------------------------------------------------ Baum-Welch statistics
+    def accumulate_stat(self, ubm, feature_server, seg_indices=None, channel_extension=("", "_b"), num_thread=1,
+                        max_batch_frames=8 * 1024 * 1024):
+        """Zero and first order statistics of the listed sessions (statserver.py:609-667).
+
+        Host side: per session, load frames, cut to [start, stop), keep VAD-selected rows
+        (statserver.py:645-652).  Device side: everything else.  `num_thread` is accepted and
+        ignored; with torch.distributed initialised the sessions are dealt to the ranks like
+        numpy.array_split and the filled rows are summed back (each row has exactly one owner).
+        """
+        assert isinstance(ubm, Mixture), 'First parameter has to be a Mixture'
+        assert hasattr(feature_server, "load"), 'Second parameter has to be a FeaturesServer'
+
+        if (seg_indices is None) \
+                or (self.stat0.shape[0] != self.segset.shape[0]) \
+                or (self.stat1.shape[0] != self.segset.shape[0]):
+            self.stat0 = np.zeros((self.segset.shape[0], ubm.distrib_nb()), dtype=STAT_TYPE)
+            self.stat1 = np.zeros((self.segset.shape[0], ubm.sv_size()), dtype=STAT_TYPE)
+            seg_indices = range(self.segset.shape[0])
+        feature_server.keep_all_features = True
+
+        seg_indices = [int(i) for i in seg_indices]
+        mine = seg_indices
+        if dist.is_dist():
+            a, b = dist.shard_bounds(len(seg_indices))
+            mine = seg_indices[a:b]
+
+        eng = self.engine
+        packed = eng.pack(ubm.w, ubm.mu, ubm.invcov)
+        C, D = ubm.distrib_nb(), ubm.dim()
+
+        batch, batch_idx, nframes = [], [], 0
+
+        def run_batch():
+            if not batch_idx:
+                return
+            lens = np.array([b.shape[0] for b in batch], dtype=np.int64)
+            seg_off = np.concatenate([[0], np.cumsum(lens)])
+            X = eng.upload_frames(np.concatenate(batch, axis=0) if len(batch) > 1 else batch[0])
+            s0, s1 = eng.bw_stats(X, seg_off, packed)
+            self.stat0[batch_idx, :] = eng.to_host(s0)
+            self.stat1[batch_idx, :] = eng.to_host(s1)
+
+        for idx in mine:
+            show = self.segset[idx]
+            channel = 0
+            if feature_server.features_extractor is not None and show.endswith(channel_extension[1]):
+                channel = 1
+            show = show[:show.rfind(channel_extension[channel])]
+            cep, vad = feature_server.load(show, channel=channel,
+                                           input_feature_filename=feature_server.feature_filename_structure)
+            if type(cep).__module__.startswith("torch"):
+                cep = cep.detach().cpu().numpy()
+            stop = vad.shape[0] if self.stop[idx] is None else min(self.stop[idx], vad.shape[0])
+            data = cep[self.start[idx]:stop, :]
+            data = data[vad[self.start[idx]:stop], :]
+            if not ubm.dim() == data.shape[1]:
+                raise Exception('dimension of ubm and features differ: {:d} / {:d}'.format(ubm.dim(), data.shape[1]))
+            batch.append(np.asarray(data, dtype=np.float32))
+            batch_idx.append(idx)
+            nframes += data.shape[0]
+            if nframes >= max_batch_frames:
+                run_batch()
+                batch, batch_idx, nframes = [], [], 0
+        run_batch()
+
+        if dist.is_dist():
+            # every requested row has exactly one owner: zero the others' rows locally, sum over ranks
+            import torch
+            owned = set(mine)
+            others = [i for i in seg_indices if i not in owned]
+            self.stat0[others, :] = 0.0
+            self.stat1[others, :] = 0.0
+            dev = eng.device if hasattr(eng, "device") else "cpu"
+            t0 = torch.as_tensor(self.stat0[seg_indices, :]).to(dev)
+            t1 = torch.as_tensor(self.stat1[seg_indices, :]).to(dev)
+            dist.allreduce_sum_(t0)
+            dist.allreduce_sum_(t1)
+            self.stat0[seg_indices, :] = t0.cpu().numpy()
+            self.stat1[seg_indices, :] = t1.cpu().numpy()
+
+    # ------------------------------------------------------------------ small algebra used around the TV path
+    def get_mean_stat1(self):
+        return np.mean(self.stat1, axis=0)
+
+    def norm_stat1(self):
+        vect_norm = np.clip(np.linalg.norm(self.stat1, axis=1), 1e-08, np.inf)
+        self.stat1 = (self.stat1.transpose() / vect_norm).transpose()
+
+    def center_stat1(self, mu):
+        """statserver.py:690-697."""
+        dim = self.stat1.shape[1] // self.stat0.shape[1]
+        index_map = np.repeat(np.arange(self.stat0.shape[1]), dim)
+        self.stat1 = self.stat1 - (self.stat0[:, index_map] * mu.astype(STAT_TYPE))
+
+    def whiten_stat1(self, mu, sigma, isSqrInvSigma=False):
+        """Diagonal whitening only (statserver.py:743-745)."""
+        if sigma.ndim != 1:
+            raise Exception('only the diagonal-covariance whitening is on this path')
+        self.center_stat1(mu)
+        self.stat1 = self.stat1 / np.sqrt(sigma.astype(STAT_TYPE))
+
+
+def _looks_like_idmap(obj):
+    return all(hasattr(obj, k) for k in ("leftids", "rightids", "start", "stop"))

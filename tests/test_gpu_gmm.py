@@ -1,0 +1,208 @@
+"""GPU parity tests of the GMM path: the HIP kernels (through the C ABI / the Python drop-in
+classes) against the CPU oracle and against the golden vectors of the real reference.
+
+Tolerance (BASELINE.json north star): UBM w / mu / cov and N / F statistics within 1e-4
+relative (float32 MFMA compute, float64 reductions).  "Relative" is measured normwise per
+array (max |delta| / max |ref|): first-order statistics of a component have entries that cancel
+to ~0, so an element-wise ratio is meaningless there; large entries are also checked
+element-wise.
+"""
+import numpy as np
+import pytest
+
+from oracle import sidekit_ref as orc
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def rel_large(a, b, frac=0.05):
+    """worst element-wise relative error over entries with |ref| >= frac * max|ref|"""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    m = np.abs(b) >= frac * np.abs(b).max()
+    return (np.abs(a - b)[m] / np.abs(b)[m]).max()
+
+
+@pytest.fixture(scope="module")
+def sk():
+    import sidekit_amd
+    return sidekit_amd
+
+
+@pytest.fixture(scope="module")
+def eng(sk):
+    return sk.default_engine()
+
+
+def unpack(flat, C, D):
+    return flat[:C], flat[C:C + C * D].reshape(C, D), flat[C + C * D:C + 2 * C * D].reshape(C, D), flat[-1]
+
+
+def run_estep(eng, gmm, cep):
+    X = eng.upload_frames(cep)
+    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    return unpack(eng.to_host(eng.estep(X, packed)), gmm.C, gmm.D)
+
+
+@pytest.mark.parametrize("tag", ["c8_d6", "c64_d60", "c40_d13"])
+def test_estep_vs_reference_golden(eng, tag):
+    g = golden("estep_%s.npz" % tag)
+    gmm = orc.GMM(g["w"], g["mu"], g["invcov"])
+    N, F, S, llk = run_estep(eng, gmm, g["cep"])
+    assert rel(N, g["N"]) < TOL
+    assert rel(F, g["F"]) < TOL
+    assert rel(S, g["S"]) < TOL
+    assert rel_large(N, g["N"]) < TOL
+    assert rel_large(S, g["S"]) < TOL
+    assert abs(llk - float(g["llk"])) < 1e-5 * abs(float(g["llk"]))
+    # M-step from the device statistics reproduces the reference's next model
+    orc.maximization(gmm, N, F, S)
+    assert rel(gmm.w, g["m_w"]) < TOL
+    assert rel(gmm.mu, g["m_mu"]) < TOL
+    assert rel(1.0 / gmm.invcov, 1.0 / g["m_invcov"]) < TOL
+
+
+@pytest.mark.parametrize("C,D,T", [(1, 60, 1000), (2, 60, 33), (33, 60, 4097), (512, 60, 20000), (96, 20, 5000),
+                                   (64, 132, 3000), (130, 7, 2049), (256, 39, 7001), (2048, 60, 6000)])
+def test_estep_vs_oracle_shapes(eng, C, D, T):
+    gmm = orc.random_gmm(C, D, seed=C + D)
+    cep = orc.synth_frames(T, dim=D, clusters=16, seed=T)
+    N, F, S, llk = run_estep(eng, gmm, cep)
+    rN, rF, rS, rl = orc.expectation(gmm, cep.astype(np.float64))
+    assert rel(N, rN) < TOL
+    assert rel(F, rF) < TOL
+    assert rel(S, rS) < TOL
+    assert abs(llk - rl) < 1e-5 * abs(rl)
+    assert abs(N.sum() - T) < 1e-4 * T          # posteriors sum to one per frame
+
+
+def test_estep_accumulate_and_empty(eng):
+    gmm = orc.random_gmm(16, 12, seed=1)
+    cep = orc.synth_frames(3000, dim=12, clusters=8, seed=2)
+    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    full = eng.to_host(eng.estep(eng.upload_frames(cep), packed))
+    out = eng.estep(eng.upload_frames(cep[:1111]), packed)
+    out = eng.estep(eng.upload_frames(cep[1111:]), packed, out=out, accumulate=True)
+    part = eng.to_host(out)
+    assert rel(part, full) < 1e-6
+    # determinism: same launch twice is bit-identical
+    again = eng.to_host(eng.estep(eng.upload_frames(cep), packed))
+    np.testing.assert_array_equal(full, again)
+
+
+def test_loglik_per_frame(eng):
+    gmm = orc.random_gmm(100, 24, seed=3)
+    cep = orc.synth_frames(2500, dim=24, clusters=8, seed=4)
+    ll = eng.to_host(eng.loglik(eng.upload_frames(cep), eng.pack(gmm.w, gmm.mu, gmm.invcov)))
+    _, ref = orc.logsumexp_rows(orc.log_posterior(gmm, cep.astype(np.float64)))
+    assert np.abs(ll - ref).max() < 2e-4 * np.abs(ref).max()
+
+
+def test_moments(eng):
+    cep = orc.synth_frames(12345, dim=60, seed=9)
+    m = eng.to_host(eng.moments(eng.upload_frames(cep)))
+    x = cep.astype(np.float64)
+    assert rel(m[:60], x.sum(0)) < 1e-12
+    assert rel(m[60:], (x ** 2).sum(0)) < 1e-12
+
+
+def _sessions(g):
+    off = np.concatenate([[0], np.cumsum(g["lens"])])
+    return [g["frames"][off[i]:off[i + 1]] for i in range(len(g["lens"]))], off
+
+
+def test_bw_stats_vs_reference_golden(eng):
+    g = golden("accumulate_stat.npz")
+    gmm = orc.GMM(g["w"], g["mu"], g["invcov"])
+    sess, off = _sessions(g)
+    s0, s1 = eng.bw_stats(eng.upload_frames(g["frames"]), off, eng.pack(gmm.w, gmm.mu, gmm.invcov))
+    s0, s1 = eng.to_host(s0), eng.to_host(s1)
+    assert rel(s0, g["stat0"]) < TOL
+    assert rel(s1, g["stat1"]) < TOL
+    # per-session normwise too (short sessions must be as accurate as long ones)
+    for i in range(len(sess)):
+        assert rel(s0[i], g["stat0"][i]) < TOL
+        assert rel(s1[i], g["stat1"][i]) < TOL
+
+
+def test_bw_stats_ragged_and_empty_sessions(eng):
+    C, D = 70, 60
+    gmm = orc.random_gmm(C, D, seed=5)
+    lens = [0, 1, 31, 32, 33, 0, 500, 64, 1]
+    frames = orc.synth_frames(sum(lens), dim=D, seed=6)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    s0, s1 = eng.bw_stats(eng.upload_frames(frames), off, eng.pack(gmm.w, gmm.mu, gmm.invcov))
+    s0, s1 = eng.to_host(s0), eng.to_host(s1)
+    r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
+    assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
+    assert np.all(s0[0] == 0) and np.all(s1[5] == 0)
+    assert np.allclose(s0.sum(1), lens, rtol=1e-4)
+
+
+def test_statserver_accumulate_stat_dropin(sk):
+    g = golden("accumulate_stat.npz")
+    sess, off = _sessions(g)
+    names = ["s%03d" % i for i in range(len(sess))]
+    fs = sk.FeaturesServer(features=dict(zip(names, sess)))
+    ubm = sk.Mixture()
+    ubm.w, ubm.mu, ubm.invcov = g["w"].copy(), g["mu"].copy(), g["invcov"].copy()
+    ubm.cov_var_ctl = 1.0 / ubm.invcov
+    ubm._compute_all()
+    idmap = sk.IdMap().set(["spk%d" % (i % 5) for i in range(len(sess))], names)
+    ss = sk.StatServer(idmap, ubm=ubm)
+    ss.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(len(sess)), num_thread=1)
+    assert ss.validate()
+    assert rel(ss.stat0, g["stat0"]) < TOL
+    assert rel(ss.stat1, g["stat1"]) < TOL
+    with pytest.raises(Exception):
+        bad = sk.FeaturesServer(features={n: np.zeros((5, ubm.dim() + 1)) for n in names})
+        ss.accumulate_stat(ubm=ubm, feature_server=bad, seg_indices=range(2))
+
+
+def test_em_split_dropin_vs_reference_golden(sk):
+    g = golden("em_split.npz")
+    chunks = {"f%d" % i: g["chunk%d" % i] for i in range(4)}
+    fs = sk.FeaturesServer(features=chunks)
+    ubm = sk.Mixture()
+    llk = ubm.EM_split(features_server=fs, feature_list=list(chunks.keys()), distrib_nb=8, num_thread=1)
+    assert len(llk) == 5
+    assert rel(np.array(llk), g["llk"]) < TOL
+    assert rel(ubm.w, g["w"]) < TOL
+    assert rel(ubm.mu, g["mu"]) < TOL
+    assert rel(1.0 / ubm.invcov, 1.0 / g["invcov"]) < TOL
+    assert rel(ubm.cov_var_ctl, g["ctl"]) < 1e-6
+    assert ubm.validate()
+
+
+def test_em_uniform_dropin_vs_reference_golden(sk):
+    g = golden("em_uniform.npz")
+    ubm = sk.Mixture()
+    llk = ubm.EM_uniform(g["cep"], 4, iteration_min=3, iteration_max=10, llk_gain=0.01, do_init=True)
+    assert len(llk) == len(g["llk"])
+    assert rel(np.array(llk), g["llk"]) < TOL
+    assert rel(ubm.w, g["w"]) < TOL
+    assert rel(ubm.mu, g["mu"]) < TOL
+    assert rel(1.0 / ubm.invcov, 1.0 / g["invcov"]) < TOL
+
+
+def test_one_em_step_from_identical_params_large(sk, eng):
+    """Step-wise parity at a size where EM is chaotic end-to-end."""
+    C, D, T = 256, 60, 60000
+    gmm = orc.random_gmm(C, D, seed=77)
+    cep = orc.synth_frames(T, dim=D, seed=78)
+    N, F, S, llk = run_estep(eng, gmm, cep)
+    rN, rF, rS, rl = orc.expectation(gmm, cep.astype(np.float64))
+    a, b = gmm.copy(), gmm.copy()
+    orc.maximization(a, N, F, S)
+    orc.maximization(b, rN, rF, rS)
+    assert rel(a.w, b.w) < TOL and rel(a.mu, b.mu) < TOL and rel(1 / a.invcov, 1 / b.invcov) < TOL
