@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X GMM-UBM / i-vector statistics hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], "UBM 512 diag comps, 60-dim synthetic MFCC, 10M frames,
+EM_split on 1 MI355X"): one STEP = one EM iteration of Mixture at C=512 -- E-step over the
+rank's 10 M float32 frames resident in HBM, one all-reduce of the packed [N|F|S|llk] float64
+buffer when N > 1, the float64 M-step and the re-pack of the model -- i.e. the body of the
+EM_split loop (reference mixture.py:686-710).  Weak scaling: every rank holds its own 10 M frames.
+`value` = frames processed by all ranks / max-over-ranks time.
+
+Also reported on the same JSON line (rank 0, N=1 detail):
+  roofline      dominant kernel (k_stats_em) against the f32 MFMA peak, timed with HIP events on
+                the launch stream inside the library (skm_prof_*), algorithmic flops only
+  roofline_path the whole E-step (8*D*C flop/frame) over the sum of its kernels
+  cpu_baseline  the NumPy float64 oracle (a port of the reference's call sequence) on a bounded
+                sample of the same workload, host cores stated
+  bw_stats      Baum-Welch N/F accumulation (configs[3] at reduced session count), frames/s
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_frames_device(torch, n, dim, seed, device, clusters=64, chunk=1 << 20):
+    """CMVN-like MFCC frames from a fixed random diagonal GMM, generated on the GPU."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    gp = torch.Generator(device=device)
+    gp.manual_seed(1234)                       # the mixture itself is the same on every rank
+    means = torch.randn(clusters, dim, generator=gp, device=device)
+    std = torch.sqrt(0.3 + 0.7 * torch.rand(clusters, dim, generator=gp, device=device))
+    out = torch.empty((n, dim), dtype=torch.float32, device=device)
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        lab = torch.randint(0, clusters, (b - a,), generator=g, device=device)
+        out[a:b] = means[lab] + std[lab] * torch.randn(b - a, dim, generator=g, device=device)
+    return out
+
+
+def random_ubm(sk, C, D, seed=7):
+    rs = np.random.RandomState(seed)
+    m = sk.Mixture()
+    m.w = rs.dirichlet(np.full(C, 5.0))
+    m.mu = rs.randn(C, D)
+    m.invcov = 1.0 / rs.uniform(0.5, 1.5, size=(C, D))
+    m.cov_var_ctl = 1.0 / m.invcov
+    m._compute_all()
+    return m
+
+
+def em_iteration(ubm, accum, X_dev):
+    """Body of the EM_split loop (mixture.py:686-710) on frames resident in HBM."""
+    accum._reset()
+    N, F, S, l = ubm._global_stats(X_dev)
+    accum.w += N
+    accum.mu += F
+    accum.invcov += S
+    llk = l / np.sum(accum.w)
+    ubm._maximization(accum)
+    return llk
+
+
+def cpu_baseline(C, D, seconds_target=15.0):
+    """The oracle's E-step + M-step (reference call sequence: 4 dot + 2 exp passes per 50k-frame
+    chunk) on a bounded sample, all host BLAS threads."""
+    from oracle import sidekit_ref as orc
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    gmm = orc.random_gmm(C, D, seed=7)
+    chunk = orc.synth_frames(50000, dim=D, seed=1234).astype(np.float64)
+    t0 = time.perf_counter()
+    orc.expectation(gmm, chunk[:10000])
+    probe = time.perf_counter() - t0
+    n_chunks = int(max(1, min(40, seconds_target / max(probe * 5.0, 1e-3))))
+    t0 = time.perf_counter()
+    N, F, S, llk = orc.expectation_chunked(gmm, [chunk] * n_chunks)
+    orc.maximization(gmm, N, F, S)
+    dt = time.perf_counter() - t0
+    frames = 50000 * n_chunks
+    return {"value": frames / dt, "unit": "frames/s", "cores": int(cores), "kind": "port",
+            "sample": "oracle (NumPy f64) E-step+M-step, C=%d D=%d, %d frames in %d chunks of 50k, %.1f s"
+                      % (C, D, frames, n_chunks, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=10_000_000, help="frames per GPU")
+    ap.add_argument("--comps", type=int, default=512)
+    ap.add_argument("--dim", type=int, default=60)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (BW stats)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as td
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        td.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    import sidekit_amd as sk
+    eng = sk.default_engine()
+    C, D, T = args.comps, args.dim, args.frames
+
+    X = synth_frames_device(torch, T, D, seed=1234 + rank, device=dev)
+    ubm = random_ubm(sk, C, D)
+    import copy
+    accum = copy.deepcopy(ubm)
+
+    def sync():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        em_iteration(ubm, accum, X)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        llk = em_iteration(ubm, accum, X)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * T * args.steps / dt
+
+    result = {
+        "metric": "frames/sec for UBM EM + Baum-Welch stats; i-vectors/sec (TV rank 400)",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "UBM EM iteration (E-step + all-reduce + M-step), C=%d diag comps, D=%d, "
+                               "%d float32 frames per GPU resident in HBM (BASELINE configs[1])" % (C, D, T),
+                   "components": C, "dim": D, "frames_per_gpu": T, "parallelism": "dp%d" % world,
+                   "final_mean_llk": float(llk)},
+    }
+
+    if rank == 0:
+        # ---- per-kernel timing with HIP events on the launch stream (separate, un-timed pass)
+        eng.profile(True)
+        nprof = 3
+        for _ in range(nprof):
+            em_iteration(ubm, accum, X)
+        torch.cuda.synchronize()
+        prof = eng.profile_read()
+        eng.profile(False)
+        kt = {k: v[1] / v[0] for k, v in prof.items()}            # avg ms per launch
+        t_stats = kt.get("k_stats_em", float("nan"))
+        t_path = sum(kt.get(k, 0.0) for k in ("k_lse_partial", "k_lse_combine", "k_stats_em", "k_reduce_slabs"))
+        flop_stats = 4.0 * D * C * T        # statistics GEMM gamma^T [x, x^2]; the recomputed logits are NOT counted
+        flop_path = 8.0 * D * C * T         # log-lik GEMM + statistics GEMM
+        ach = flop_stats / (t_stats * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": "k_stats_em", "achieved": ach,
+                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                              "traffic": None, "avg_launch_ms": t_stats,
+                              "algorithmic_flop_per_launch": flop_stats}
+        achp = flop_path / (t_path * 1e-3) / 1e12
+        result["roofline_path"] = {"bound": "mfma", "kernels": {k: round(v, 4) for k, v in kt.items()},
+                                   "achieved": achp, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": achp / PEAK_F32_MFMA_TFLOPS, "algorithmic_flop_per_step": flop_path,
+                                   "issued_mfma_flop_per_step": (4.0 * D * C + 4.0 * D * C + 4.0 * 64 * C) * T}
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        # ---- Baum-Welch N/F accumulation (BASELINE configs[3], fewer sessions): C=2048, 2000-frame sessions
+        Cb, S, L = 2048, min(5000, T // 2000), 2000
+        ubm_b = random_ubm(sk, Cb, D, seed=11)
+        packed = eng.pack(ubm_b.w, ubm_b.mu, ubm_b.invcov)
+        seg = torch.arange(0, S + 1, dtype=torch.int64, device=dev) * L
+        Xb = X[:S * L]
+        s0 = torch.empty((S, Cb), dtype=torch.float64, device=dev)
+        s1 = torch.empty((S, Cb * D), dtype=torch.float64, device=dev)
+        eng.bw_stats(Xb, seg, packed, s0, s1)
+        torch.cuda.synchronize()
+        eng.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            eng.bw_stats(Xb, seg, packed, s0, s1)
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - t0) / 2
+        prof = eng.profile_read()
+        eng.profile(False)
+        t_bw = prof["k_stats_bw"][1] / prof["k_stats_bw"][0]
+        result["bw_stats"] = {"value": S * L / dtb, "unit": "frames/s",
+                              "workload": "accumulate_stat body, C=%d, %d sessions x %d frames" % (Cb, S, L),
+                              "roofline": {"bound": "mfma", "kernel": "k_stats_bw",
+                                           "achieved": 2.0 * D * Cb * S * L / (t_bw * 1e-3) / 1e12,
+                                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": 2.0 * D * Cb * S * L / (t_bw * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                           "avg_launch_ms": t_bw},
+                              "path_frac_of_mfma_peak": 6.0 * D * Cb * S * L / dtb / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        del s0, s1
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(C, D)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

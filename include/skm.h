@@ -42,6 +42,13 @@ int skm_ctx_create(int device, void **ctx);
 int skm_ctx_destroy(void *ctx);
 int skm_ctx_cu_count(void *ctx);
 
+/* Per-kernel timing for bench.py's roofline: when enabled, every kernel launch of the library is
+ * bracketed by HIP events recorded on the launch stream.  skm_prof_read waits for them, writes
+ * one text line "kernel_name launches total_ms" per kernel into buf and clears the records;
+ * returns the number of bytes written.  No counterpart in the reference (it has no profiling). */
+int  skm_prof_enable(void *ctx, int on);
+long skm_prof_read(void *ctx, char *buf, size_t cap);
+
 /* ------------------------------------------------------------------ diagonal GMM ------ */
 
 /* Bytes of the packed, MFMA-fragment-ordered GMM image for C components of dimension D. */

@@ -16,9 +16,39 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 #define SKM_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline).
+struct SkmProfRec {
+    const char *name;
+    hipEvent_t a, b;
+};
+
 struct SkmCtx {
     int device;
     int cu_count;
+    int prof_on;
+    std::vector<SkmProfRec> prof;
+};
+
+struct SkmProfScope {
+    SkmCtx *ctx;
+    hipStream_t st;
+    hipEvent_t a, b;
+    const char *name;
+    bool on;
+    SkmProfScope(SkmCtx *c, const char *n, hipStream_t s) : ctx(c), st(s), name(n), on(c && c->prof_on)
+    {
+        if (on) {
+            on = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
+            if (on) (void)hipEventRecord(a, st);
+        }
+    }
+    ~SkmProfScope()
+    {
+        if (on) {
+            (void)hipEventRecord(b, st);
+            ctx->prof.push_back(SkmProfRec{name, a, b});
+        }
+    }
 };
 
 void skm_set_error(const char *fmt, ...);

@@ -56,6 +56,7 @@ extern "C" int skm_ctx_create(int device, void **ctx)
     SkmCtx *c = new SkmCtx();
     c->device = device;
     c->cu_count = prop.multiProcessorCount;
+    c->prof_on = 0;
     *ctx = c;
     return SKM_OK;
 }
@@ -67,6 +68,52 @@ extern "C" int skm_ctx_destroy(void *ctx)
 }
 
 extern "C" int skm_ctx_cu_count(void *ctx) { return ctx ? static_cast<SkmCtx *>(ctx)->cu_count : 0; }
+
+extern "C" int skm_prof_enable(void *ctx_, int on)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx != nullptr, "skm_prof_enable: NULL ctx");
+    ctx->prof_on = on ? 1 : 0;
+    return SKM_OK;
+}
+
+// Waits for every recorded event, writes one line "name count total_ms" per kernel name into buf
+// and clears the records.  Returns the number of bytes written (excluding the NUL), <0 on error.
+extern "C" long skm_prof_read(void *ctx_, char *buf, size_t cap)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && buf && cap > 0, "skm_prof_read: bad argument");
+    struct Agg {
+        const char *name;
+        long n;
+        double ms;
+    };
+    std::vector<Agg> agg;
+    for (SkmProfRec &r : ctx->prof) {
+        float ms = 0.f;
+        SKM_HIP(hipEventSynchronize(r.b));
+        SKM_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+        bool found = false;
+        for (Agg &g : agg)
+            if (strcmp(g.name, r.name) == 0) {
+                g.n++;
+                g.ms += ms;
+                found = true;
+            }
+        if (!found) agg.push_back(Agg{r.name, 1, ms});
+    }
+    ctx->prof.clear();
+    size_t off = 0;
+    buf[0] = 0;
+    for (Agg &g : agg) {
+        int w = snprintf(buf + off, cap - off, "%s %ld %.6f\n", g.name, g.n, g.ms);
+        if (w < 0 || (size_t)w >= cap - off) break;
+        off += (size_t)w;
+    }
+    return (long)off;
+}
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -735,8 +782,8 @@ static int set_lds(K kernel, size_t bytes)
     return SKM_OK;
 }
 
-static int launch_lse(const Plan &p, const float *X, long T, const float *wp, const float *kc, char *ws,
-                      float *loglik, hipStream_t st)
+static int launch_lse(SkmCtx *ctx, const Plan &p, const float *X, long T, const float *wp, const float *kc,
+                      char *ws, float *loglik, hipStream_t st)
 {
     LseArgs a;
     a.X = X;
@@ -750,19 +797,22 @@ static int launch_lse(const Plan &p, const float *X, long T, const float *wp, co
     a.n_fs = p.n_fs1;
     const dim3 grid(p.n_cb1 * p.n_fs1), block(64 * p.nw1);
     int rc = SKM_OK;
-    switch (p.nct1) {
-    case 4:
-        if ((rc = set_lds(k_lse_partial<4>, p.lds1))) return rc;
-        hipLaunchKernelGGL(k_lse_partial<4>, grid, block, p.lds1, st, a);
-        break;
-    case 2:
-        if ((rc = set_lds(k_lse_partial<2>, p.lds1))) return rc;
-        hipLaunchKernelGGL(k_lse_partial<2>, grid, block, p.lds1, st, a);
-        break;
-    default:
-        if ((rc = set_lds(k_lse_partial<1>, p.lds1))) return rc;
-        hipLaunchKernelGGL(k_lse_partial<1>, grid, block, p.lds1, st, a);
-        break;
+    {
+        SkmProfScope ps(ctx, "k_lse_partial", st);
+        switch (p.nct1) {
+        case 4:
+            if ((rc = set_lds(k_lse_partial<4>, p.lds1))) return rc;
+            hipLaunchKernelGGL(k_lse_partial<4>, grid, block, p.lds1, st, a);
+            break;
+        case 2:
+            if ((rc = set_lds(k_lse_partial<2>, p.lds1))) return rc;
+            hipLaunchKernelGGL(k_lse_partial<2>, grid, block, p.lds1, st, a);
+            break;
+        default:
+            if ((rc = set_lds(k_lse_partial<1>, p.lds1))) return rc;
+            hipLaunchKernelGGL(k_lse_partial<1>, grid, block, p.lds1, st, a);
+            break;
+        }
     }
     SKM_HIP(hipGetLastError());
     long nb = (T + 255) / 256;
@@ -770,33 +820,38 @@ static int launch_lse(const Plan &p, const float *X, long T, const float *wp, co
     if (nb < 1) nb = 1;
     // unused partial slots must read as zero
     SKM_HIP(hipMemsetAsync(ws + p.off_llk, 0, p.n_llk * sizeof(double), st));
-    hipLaunchKernelGGL(k_lse_combine, dim3((unsigned)nb), dim3(256), 0, st, a.pm, a.ps, p.n_cb1, T,
-                       reinterpret_cast<float *>(ws + p.off_lse), loglik, reinterpret_cast<double *>(ws + p.off_llk));
+    {
+        SkmProfScope ps(ctx, "k_lse_combine", st);
+        hipLaunchKernelGGL(k_lse_combine, dim3((unsigned)nb), dim3(256), 0, st, a.pm, a.ps, p.n_cb1, T,
+                           reinterpret_cast<float *>(ws + p.off_lse), loglik,
+                           reinterpret_cast<double *>(ws + p.off_llk));
+    }
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }
 
 template <int NJT, bool WITH_S, bool BW>
-static int launch_stats_t(const Plan &p, const StatsArgs &a, hipStream_t st)
+static int launch_stats_t(SkmCtx *ctx, const Plan &p, const StatsArgs &a, hipStream_t st)
 {
     constexpr int NF = NJT * (WITH_S ? 2 : 1);
     constexpr int NCT = (NF <= 4) ? 2 : 1;
     int rc = set_lds(k_stats<NJT, NCT, WITH_S, BW>, p.lds2);
     if (rc) return rc;
+    SkmProfScope ps(ctx, BW ? "k_stats_bw" : "k_stats_em", st);
     hipLaunchKernelGGL((k_stats<NJT, NCT, WITH_S, BW>), dim3(p.n_cb2 * p.n_fs2), dim3(64 * p.nw2), p.lds2, st, a);
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }
 
 template <bool WITH_S, bool BW>
-static int launch_stats(const Plan &p, const StatsArgs &a, hipStream_t st)
+static int launch_stats(SkmCtx *ctx, const Plan &p, const StatsArgs &a, hipStream_t st)
 {
     switch (p.g.NJT) {
-    case 1: return launch_stats_t<1, WITH_S, BW>(p, a, st);
-    case 2: return launch_stats_t<2, WITH_S, BW>(p, a, st);
-    case 3: return launch_stats_t<3, WITH_S, BW>(p, a, st);
-    case 4: return launch_stats_t<4, WITH_S, BW>(p, a, st);
-    case 5: return launch_stats_t<5, WITH_S, BW>(p, a, st);
+    case 1: return launch_stats_t<1, WITH_S, BW>(ctx, p, a, st);
+    case 2: return launch_stats_t<2, WITH_S, BW>(ctx, p, a, st);
+    case 3: return launch_stats_t<3, WITH_S, BW>(ctx, p, a, st);
+    case 4: return launch_stats_t<4, WITH_S, BW>(ctx, p, a, st);
+    case 5: return launch_stats_t<5, WITH_S, BW>(ctx, p, a, st);
     }
     skm_set_error("unsupported NJT=%d", p.g.NJT);
     return SKM_ERR_UNSUPPORTED;
@@ -833,7 +888,7 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
     char *ws = static_cast<char *>(ws_);
     const float *wp = static_cast<const float *>(packed);
     const float *kc = wp + (size_t)p.g.CTpad * p.g.NCH * 256;
-    if ((rc = launch_lse(p, X, T, wp, kc, ws, nullptr, st))) return rc;
+    if ((rc = launch_lse(ctx, p, X, T, wp, kc, ws, nullptr, st))) return rc;
     StatsArgs a;
     memset(&a, 0, sizeof(a));
     a.X = X;
@@ -848,11 +903,14 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
     a.slabs = reinterpret_cast<double *>(ws + p.off_slabs);
     SKM_HIP(hipMemsetAsync(a.slabs, 0,
                            (size_t)p.n_cb2 * p.n_fs2 * p.nw2 * p.nct2 * 32 * p.nf2 * 32 * sizeof(double), st));
-    if ((rc = launch_stats<true, false>(p, a, st))) return rc;
+    if ((rc = launch_stats<true, false>(ctx, p, a, st))) return rc;
     const long n_out = (long)C * p.nf2 * 32;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, a.slabs, p.n_cb2,
-                       p.n_fs2, p.nw2, p.nct2, p.g.NJT, p.nf2, C, D, out, accumulate,
-                       reinterpret_cast<const double *>(ws + p.off_llk), p.n_llk);
+    {
+        SkmProfScope ps(ctx, "k_reduce_slabs", st);
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, a.slabs,
+                           p.n_cb2, p.n_fs2, p.nw2, p.nct2, p.g.NJT, p.nf2, C, D, out, accumulate,
+                           reinterpret_cast<const double *>(ws + p.off_llk), p.n_llk);
+    }
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }
@@ -869,7 +927,7 @@ extern "C" int skm_gmm_loglik(void *ctx_, const float *X, long T, int C, int D, 
     SKM_REQUIRE(loglik != nullptr, "skm_gmm_loglik: loglik is NULL");
     const float *wp = static_cast<const float *>(packed);
     const float *kc = wp + (size_t)p.g.CTpad * p.g.NCH * 256;
-    return launch_lse(p, X, T, wp, kc, static_cast<char *>(ws_), loglik, (hipStream_t)stream);
+    return launch_lse(ctx, p, X, T, wp, kc, static_cast<char *>(ws_), loglik, (hipStream_t)stream);
 }
 
 extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *seg_off, int S, int C, int D,
@@ -888,7 +946,7 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
     char *ws = static_cast<char *>(ws_);
     const float *wp = static_cast<const float *>(packed);
     const float *kc = wp + (size_t)p.g.CTpad * p.g.NCH * 256;
-    if ((rc = launch_lse(p, X, T, wp, kc, ws, nullptr, st))) return rc;
+    if ((rc = launch_lse(ctx, p, X, T, wp, kc, ws, nullptr, st))) return rc;
     StatsArgs a;
     memset(&a, 0, sizeof(a));
     a.X = X;
@@ -904,7 +962,7 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
     a.S = S;
     a.stat0 = stat0;
     a.stat1 = stat1;
-    return launch_stats<false, true>(p, a, st);
+    return launch_stats<false, true>(ctx, p, a, st);
 }
 
 extern "C" size_t skm_moments_workspace_bytes(void *ctx_, int D)

@@ -26,6 +26,8 @@ SIGNATURES = {
     "skm_ctx_create": (_c_int, [_c_int, ctypes.POINTER(_c_void_p)]),
     "skm_ctx_destroy": (_c_int, [_c_void_p]),
     "skm_ctx_cu_count": (_c_int, [_c_void_p]),
+    "skm_prof_enable": (_c_int, [_c_void_p, _c_int]),
+    "skm_prof_read": (_c_long, [_c_void_p, ctypes.c_char_p, _c_size_t]),
     "skm_gmm_packed_bytes": (_c_size_t, [_c_int, _c_int]),
     "skm_gmm_pack": (_c_int, [_c_void_p, _dp, _dp, _dp, _c_int, _c_int, _c_void_p, _c_void_p]),
     "skm_gmm_workspace_bytes": (_c_size_t, [_c_void_p, _c_long, _c_int, _c_int]),
@@ -209,6 +211,22 @@ class HipEngine(object):
         ws = self.workspace(need)
         self._check(self.lib.skm_moments(self.ctx, _c_void_p(X.data_ptr()), T, D, _c_void_p(out.data_ptr()),
                                          _c_void_p(ws), need, self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ per-kernel timing (HIP events)
+    def profile(self, on):
+        self._check(self.lib.skm_prof_enable(self.ctx, 1 if on else 0))
+
+    def profile_read(self):
+        """{kernel name: (launches, total_ms)} since the last read; waits for the events."""
+        buf = ctypes.create_string_buffer(8192)
+        n = self.lib.skm_prof_read(self.ctx, buf, 8192)
+        if n < 0:
+            self._check(int(n))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
         return out
 
     # ------------------------------------------------------------------ host conveniences
