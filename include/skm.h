@@ -99,6 +99,57 @@ size_t skm_moments_workspace_bytes(void *ctx, int D);
 int skm_moments(void *ctx, const float *X_dev, long T, int D, double *out_dev,
                 void *ws_dev, size_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------------------ total variability ---- */
+
+/* GEMM kinds of skm_gemm: input/compute type -> storage type of C. */
+#define SKM_GEMM_F32_F32    0  /* float MFMA (v_mfma_f32_32x32x2_f32), C float                         */
+#define SKM_GEMM_F32_F64ACC 1  /* float MFMA, accumulators folded into float64 every 512 k, C double   */
+#define SKM_GEMM_F64_F64    2  /* double MFMA (v_mfma_f64_16x16x4_f64), C double                        */
+#define SKM_GEMM_F64_F32OUT 3  /* double MFMA, C float                                                  */
+
+/* Strided-batched row-major GEMM  C[z] = alpha op(A[z]) op(B[z]) + beta C[z]  (all pointers dev; trans
+ * flags mean "stored transposed").  Replaces the numpy.dot call sites of the TV path that are plain
+ * products, e.g. the minimum-divergence update F.dot(ch) (sidekit/factor_analyser.py:665). */
+int skm_gemm(void *ctx, int kind, const void *A, const void *B, void *C, int M, int N, int K, long lda, long ldb,
+             long ldc, int transA, int transB, double alpha, double beta, int batch, long sA, long sB, long sC,
+             void *stream);
+
+/* Workspace bytes of skm_tv_estep (S sessions) / skm_tv_mstep (pass S = 0) for a given batch. */
+size_t skm_tv_workspace_bytes(void *ctx, int C, int D, int R, long S, int batch);
+
+/* Centre and whiten first-order statistics and build the augmented zero-order matrix:
+ *   ftilde[S*C*D] float32 = (stat1 - stat0[:,c] * mu) * sqrt(invcov)   with the reference's rounding (in
+ *   place in the INPUT dtype: float32 statistics are rounded to float32 after each of the two updates),
+ *   naug[S*(C+1)] float32 = [stat0 | 1].
+ * in_f64 = 0: stat0/stat1 are float32 (statistics read from a StatServer file), 1: float64.
+ * Replaces sidekit/factor_analyser.py:76-79 (and StatServer.whiten_stat1, statserver.py:743-745). */
+int skm_tv_whiten(void *ctx, const void *stat0_dev, const void *stat1_dev, int in_f64, long S, int C, int D,
+                  const double *mu_dev, const double *sqrt_invcov_dev, float *ftilde_dev, float *naug_dev,
+                  void *stream);
+
+/* Once per EM iteration: T32 = float(T) and the Gram matrices G_c = T_c' T_c (G_dev[C*R*R] float32, only
+ * the blocks on/above the 32-block diagonal are written).  T_dev is the CD x R loading matrix (float64).
+ * Replaces the per-session product (F.T * stat0[idx, index_map]).dot(F) of factor_analyser.py:87 by
+ * L_s = I + sum_c N_sc G_c. */
+int skm_tv_prepare(void *ctx, const double *T_dev, int C, int D, int R, float *T32_dev, float *G_dev, void *stream);
+
+/* TV E-step over S sessions (batches of `batch`):
+ *   e_h_dev[S*R]        float64  posterior means (= the i-vectors)
+ *   iv_sigma_dev[S*R]   float64  diag(L^-1) + e_h^2, or NULL        (factor_analyser.py:142)
+ *   A_aug_dev[(C+1)*R*R] float64 += N' e_hh per component; row C accumulates sum_s e_hh (= _R); full
+ *                       [R][R] storage, only blocks on/above the 32-block diagonal are touched; or NULL
+ *   Cacc_dev[R*C*D]     float64 += e_h' ftilde; or NULL (A_aug and Cacc go together: training)
+ * Replaces e_on_batch (factor_analyser.py:52-92), e_gather (:109-128), iv_extract_on_batch (:131-142). */
+int skm_tv_estep(void *ctx, const float *naug_dev, const float *ftilde_dev, long S, int C, int D, int R,
+                 const float *T32_dev, const float *G_dev, int batch, double *A_aug_dev, double *Cacc_dev,
+                 double *e_h_dev, double *iv_sigma_dev, void *ws_dev, size_t ws_bytes, void *stream);
+
+/* TV M-step: F_out_dev[C*D*R] = per component (A_c^-1 C_c)'; A_aug rows 0..C-1 are destroyed.
+ * Replaces the solve loop of factor_analyser.py:653-658 (the reference's LU solve of the SPD system is
+ * done by a blocked Cholesky inverse).  Minimum divergence (:661-665) = skm_gemm with chol(R). */
+int skm_tv_mstep(void *ctx, double *A_aug_dev, const double *Cacc_dev, int C, int D, int R, int batch,
+                 double *F_out_dev, void *ws_dev, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

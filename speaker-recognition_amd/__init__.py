@@ -6,6 +6,7 @@ from .idmap import IdMap  # noqa: F401
 from .features_server import FeaturesServer  # noqa: F401
 from .mixture import Mixture  # noqa: F401
 from .statserver import StatServer  # noqa: F401
+from .factor_analyser import FactorAnalyser  # noqa: F401
 from . import dist  # noqa: F401
 
 PARAM_TYPE = "float32"

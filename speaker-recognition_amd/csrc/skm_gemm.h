@@ -1,0 +1,62 @@
+// skm_gemm.h -- generic strided-batched MFMA GEMM for gfx950 used by the TV path.
+//
+//   C[z] = alpha * op(A[z]) * op(B[z]) + beta * C[z]        (row-major, leading dimensions in elements)
+//
+// TI = float  -> v_mfma_f32_32x32x2_f32, block tile 128 x 128, BK 16
+// TI = double -> v_mfma_f64_16x16x4_f64, block tile  64 x  64, BK 16
+// TO is the storage type of C (float or double).  With ACC64 (TI = float only) the f32 MFMA
+// accumulators are folded into float64 registers every 256 k-steps so that long reductions
+// (K = C*D = 122 880 for the TV first-order projection) keep float64-grade sums.
+//
+// Extras used by the blocked Cholesky / TV E-step:
+//   tile_mask  0: all of C, 1: only the 32 x 32 blocks of C on or above the block diagonal (column block >=
+//              row block) are written; everything else of C is left untouched
+//   tri_n > 0  "triangular rows" batch mode: batch z is row z of a [tri_n x tri_n] matrix stored behind
+//              B and C (row stride tri_ldz); only columns >= col0(z) = (z / tri_blk) * tri_blk are produced:
+//              B += z*tri_ldz + col0, C += z*tri_ldz + col0, N = tri_n - col0.  (A is shared.)
+#pragma once
+#include "skm_common.h"
+
+struct GemmArgs {
+    const void *A;
+    const void *B;
+    void *C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    long sA, sB, sC;
+    int transA, transB;  // transX: the matrix is stored transposed (A as K x M, B as N x K)
+    double alpha, beta;
+    int tile_mask;
+    int mask_blk;  // block size of tile_mask (32)
+    int tri_n, tri_blk;
+    long tri_ldz;
+};
+
+static inline GemmArgs skm_gemm_args(const void *A, const void *B, void *C, int M, int N, int K, long lda,
+                                     long ldb, long ldc)
+{
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A;
+    g.B = B;
+    g.C = C;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.lda = lda;
+    g.ldb = ldb;
+    g.ldc = ldc;
+    g.alpha = 1.0;
+    g.beta = 0.0;
+    g.mask_blk = 32;
+    return g;
+}
+
+// GEMM kinds: SKM_GEMM_* in include/skm.h
+
+// kind: input/compute type and output type
+//   SKM_GEMM_F32_F32     A,B float,  C float
+//   SKM_GEMM_F32_F64ACC  A,B float,  C double (f64 folding of the accumulators)
+//   SKM_GEMM_F64_F64     A,B double, C double
+//   SKM_GEMM_F64_F32OUT  A,B double, C float
+int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStream_t st, const char *tag);

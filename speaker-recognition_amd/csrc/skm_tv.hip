@@ -1,0 +1,395 @@
+// skm_tv.hip -- total-variability (i-vector) E-step / M-step for gfx950 (MI355X).
+//
+// Replaces (reference = SIDEKIT 1.3.2 fork):
+//   sidekit/factor_analyser.py:52-92    e_on_batch      (whitening, per-session inv(I + T' diag(N) T), e_h, e_hh)
+//   sidekit/factor_analyser.py:109-128  e_gather        (_A += N' e_hh, _C += e_h' f~, _R += sum e_hh)
+//   sidekit/factor_analyser.py:131-164  iv_extract_on_batch / iv_collect
+//   sidekit/factor_analyser.py:653-658  M-step, per component solve(A_c, C_c).T
+//
+// Formulation.  T is the CD x R loading matrix in the whitened space.
+//   prepare : G_c = T_c' T_c for every component (R x R, f64 MFMA -> f32), T32 = float(T)
+//   E-step  : aux = f~ T                       one GEMM over all sessions   (f32 MFMA, f64 folding)
+//             per batch of sessions:
+//               L_s = I + sum_c N_sc G_c       GEMM  [B x C] . [C x R*R]     (f32 MFMA, f64 folding), upper rows only
+//               L_s^-1                         blocked upper Cholesky + triangular inverse + X X' (f64 MFMA GEMMs
+//                                              over the batch, 32x32 diagonal blocks factored in LDS)
+//               e_h = L^-1 aux, e_hh = L^-1 + e_h e_h'   (per-session kernel)
+//               A[c] += sum_s N_sc e_hh(s)     GEMM  [C+1 x B] . [B x R*R]; the extra row of ones yields _R
+//             C += e_h' f~                     one GEMM over all sessions
+//   M-step  : A_c^-1 through the same blocked inverse (batch = components), T_c = C_c' A_c^-1
+// Symmetric R x R matrices are kept in full [R][R] row-major storage; only the part of each row at or right
+// of its 32-aligned diagonal block is produced/consumed ("triangular rows" mode of the GEMM), the rest is
+// never read except where the buffer was zero-filled.
+#include "skm_gemm.h"
+
+#define TV_BLK 32
+
+// ------------------------------------------------------------------------------------------------
+// whitening (factor_analyser.py:76-79): in place in the input dtype in the reference; with float32
+// statistics every update is computed in float64 and rounded to float32, which is reproduced here.
+// ------------------------------------------------------------------------------------------------
+template <typename TS>
+__global__ __launch_bounds__(256) void k_tv_whiten(const TS *__restrict__ stat0, const TS *__restrict__ stat1,
+                                                   long S, int C, int D, const double *__restrict__ mu,
+                                                   const double *__restrict__ sqrt_ic, float *__restrict__ ft,
+                                                   float *__restrict__ naug)
+{
+    const long CD = (long)C * D;
+    const long total = S * CD;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long s = i / CD;
+        const int idx = (int)(i - s * CD);
+        const int c = idx / D;
+        const double n = (double)stat0[s * C + c];
+        if (sizeof(TS) == 4) {
+            const float t1 = (float)((double)stat1[i] - n * mu[idx]);
+            ft[i] = (float)((double)t1 * sqrt_ic[idx]);
+        } else {
+            ft[i] = (float)(((double)stat1[i] - n * mu[idx]) * sqrt_ic[idx]);
+        }
+    }
+    const long totn = S * (C + 1);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < totn; i += (long)gridDim.x * blockDim.x) {
+        const long s = i / (C + 1);
+        const int c = (int)(i - s * (C + 1));
+        naug[i] = (c < C) ? (float)stat0[s * C + c] : 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cvt_f64_f32(const double *__restrict__ src, float *__restrict__ dst, long n)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = (float)src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// diagonal block of the blocked Cholesky: U = chol_upper(M_kk) (n <= 32), then W = U^-1 written back in
+// place (upper triangular, strictly lower part zeroed).  One wave per matrix, block in LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_chol_diag(double *__restrict__ Mb, long stride, int ld, int n, int add_identity)
+{
+    __shared__ double a[TV_BLK][TV_BLK + 1];
+    __shared__ double x[TV_BLK][TV_BLK + 1];
+    double *M = Mb + (long)blockIdx.x * stride;
+    const int t = threadIdx.x;
+    for (int e = t; e < TV_BLK * TV_BLK; e += 64) {
+        const int r = e / TV_BLK, c = e % TV_BLK;
+        double v = 0.0;
+        if (r < n && c < n && c >= r) v = M[(long)r * ld + c];
+        if (add_identity && r == c && r < n) v += 1.0;
+        a[r][c] = v;
+        x[r][c] = 0.0;
+    }
+    __syncthreads();
+    // right-looking upper Cholesky: row j is scaled, then the trailing upper block is updated
+    for (int j = 0; j < n; ++j) {
+        const double d = sqrt(a[j][j]);
+        __syncthreads();
+        if (t == j) a[j][j] = d;
+        if (t > j && t < n) a[j][t] /= d;
+        __syncthreads();
+        for (int e = t; e < TV_BLK * TV_BLK; e += 64) {
+            const int r = e / TV_BLK, c = e % TV_BLK;
+            if (r > j && c >= r && c < n) a[r][c] -= a[j][r] * a[j][c];
+        }
+        __syncthreads();
+    }
+    // X = U^-1, one column per thread (back substitution)
+    if (t < n) {
+        const int c = t;
+        x[c][c] = 1.0 / a[c][c];
+        for (int i = c - 1; i >= 0; --i) {
+            double s = 0.0;
+            for (int l = i + 1; l <= c; ++l) s += a[i][l] * x[l][c];
+            x[i][c] = -s / a[i][i];
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < TV_BLK * TV_BLK; e += 64) {
+        const int r = e / TV_BLK, c = e % TV_BLK;
+        if (r < n && c < n) M[(long)r * ld + c] = x[r][c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per session: e_h = L^-1 aux (L^-1 symmetric, upper part valid), e_hh = L^-1 + e_h e_h'
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tv_finish(const double *__restrict__ Linv, int R, const double *__restrict__ aux,
+                                                   double *__restrict__ e_h, float *__restrict__ e_h32,
+                                                   double *__restrict__ iv_sigma, float *__restrict__ E)
+{
+    extern __shared__ double sh[];  // aux[R], y[R]
+    double *ax = sh, *y = sh + R;
+    const long b = blockIdx.x;
+    const double *Li = Linv + b * (long)R * R;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < R; i += 256) {
+        ax[i] = aux[b * R + i];
+        y[i] = 0.0;
+    }
+    __syncthreads();
+    // y[j] = sum_{i<=j} U[i][j] ax[i]   (column sweep, coalesced along j)
+    for (int j = t; j < R; j += 256) {
+        double s = 0.0;
+        for (int i = 0; i <= j; ++i) s += Li[(long)i * R + j] * ax[i];
+        y[j] = s;
+    }
+    __syncthreads();
+    // y[i] += sum_{j>i} U[i][j] ax[j]   (row reduce, one wave per row)
+    for (int i = wave; i < R; i += 4) {
+        double s = 0.0;
+        for (int j = i + 1 + lane; j < R; j += 64) s += Li[(long)i * R + j] * ax[j];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+        if (lane == 0) y[i] += s;
+    }
+    __syncthreads();
+    for (int i = t; i < R; i += 256) {
+        const double v = y[i];
+        e_h[b * R + i] = v;
+        if (e_h32) e_h32[b * R + i] = (float)v;
+        if (iv_sigma) iv_sigma[b * R + i] = Li[(long)i * R + i] + v * v;
+    }
+    if (E) {
+        float *Eb = E + b * (long)R * R;
+        for (int i = wave; i < R; i += 4) {
+            const int col0 = (i / TV_BLK) * TV_BLK;
+            const double yi = y[i];
+            for (int j = col0 + lane; j < R; j += 64) {
+                // inside the diagonal block the strictly-lower entries mirror the upper ones
+                const double l = (j >= i) ? Li[(long)i * R + j] : Li[(long)j * R + i];
+                Eb[(long)i * R + j] = (float)(l + yi * y[j]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------------
+// In-place inverse of `nb` SPD matrices (upper part valid, everything else of the buffer ZERO):
+//   Mb  [nb][R][R] f64, destroyed (ends as X = U^-1)
+//   out [nb][R][R] f64 = M^-1 (upper 64-tiles only when upper_only)
+//   Tb  [nb][32][R] f64 scratch
+static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int nb, int R, int add_identity,
+                           int upper_only, hipStream_t st)
+{
+    const long RR = (long)R * R;
+    const int Kb = (R + TV_BLK - 1) / TV_BLK;
+    int rc;
+    for (int k = 0; k < Kb; ++k) {
+        const int r0 = k * TV_BLK, bs = (R - r0 < TV_BLK) ? (R - r0) : TV_BLK, rem = R - r0 - bs;
+        {
+            SkmProfScope ps(ctx, "k_chol_diag", st);
+            hipLaunchKernelGGL(k_chol_diag, dim3(nb), dim3(64), 0, st, Mb + (long)r0 * R + r0, RR, R, bs, add_identity);
+        }
+        SKM_HIP(hipGetLastError());
+        if (rem <= 0) continue;
+        double *panel = Mb + (long)r0 * R + r0 + bs;
+        // U[k, j>k] = W_k' M[k, j>k]   (in place: every tile reads its whole K range before it writes)
+        GemmArgs g = skm_gemm_args(Mb + (long)r0 * R + r0, panel, panel, bs, rem, bs, R, R, R);
+        g.transA = 1;
+        g.sA = g.sB = g.sC = RR;
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, g, nb, st, "k_gemm_chol_panel"))) return rc;
+        // M[i, j] -= U[k,i]' U[k,j]   i, j > k, upper tiles only
+        GemmArgs u = skm_gemm_args(panel, panel, Mb + (long)(r0 + bs) * R + r0 + bs, rem, rem, bs, R, R, R);
+        u.transA = 1;
+        u.alpha = -1.0;
+        u.beta = 1.0;
+        u.tile_mask = 1;
+        u.sA = u.sB = u.sC = RR;
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, u, nb, st, "k_gemm_chol_update"))) return rc;
+    }
+    // X = U^-1 in place, block rows bottom-up (diagonal blocks already hold W_i = U_ii^-1)
+    for (int i = Kb - 2; i >= 0; --i) {
+        const int r0 = i * TV_BLK, bs = TV_BLK, c0 = r0 + bs, rem = R - c0;
+        GemmArgs t = skm_gemm_args(Mb + (long)r0 * R + c0, Mb + (long)c0 * R + c0, Tb, bs, rem, rem, R, R, R);
+        t.sA = t.sB = RR;
+        t.sC = (long)TV_BLK * R;
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, t, nb, st, "k_gemm_trinv_a"))) return rc;
+        GemmArgs x = skm_gemm_args(Mb + (long)r0 * R + r0, Tb, Mb + (long)r0 * R + c0, bs, rem, bs, R, R, R);
+        x.alpha = -1.0;
+        x.sA = x.sC = RR;
+        x.sB = (long)TV_BLK * R;
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, x, nb, st, "k_gemm_trinv_b"))) return rc;
+    }
+    // M^-1 = X X'
+    GemmArgs p = skm_gemm_args(Mb, Mb, out, R, R, R, R, R, R);
+    p.transB = 1;
+    p.tile_mask = upper_only ? 1 : 0;
+    p.sA = p.sB = p.sC = RR;
+    return skm_gemm_launch(ctx, SKM_GEMM_F64_F64, p, nb, st, "k_gemm_xxt");
+}
+
+struct TvWs {
+    size_t off_mb, off_linv, off_e, off_tb, off_aux, off_eh32, total;
+};
+
+static TvWs tv_ws(int R, long S, int batch)
+{
+    TvWs w;
+    const size_t RR = (size_t)R * R;
+    size_t off = 0;
+    w.off_mb = off;
+    off += skm_align_up((size_t)batch * RR * sizeof(double), 256);
+    w.off_linv = off;
+    off += skm_align_up((size_t)batch * RR * sizeof(double), 256);
+    w.off_e = off;
+    off += skm_align_up((size_t)batch * RR * sizeof(float), 256);
+    w.off_tb = off;
+    off += skm_align_up((size_t)batch * TV_BLK * R * sizeof(double), 256);
+    w.off_aux = off;
+    off += skm_align_up((size_t)S * R * sizeof(double), 256);
+    w.off_eh32 = off;
+    off += skm_align_up((size_t)S * R * sizeof(float), 256);
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t skm_tv_workspace_bytes(void *ctx, int C, int D, int R, long S, int batch)
+{
+    (void)ctx;
+    (void)C;
+    (void)D;
+    if (R <= 0 || S < 0 || batch <= 0) return 0;
+    return tv_ws(R, S, batch).total;
+}
+
+extern "C" int skm_tv_whiten(void *ctx_, const void *stat0, const void *stat1, int in_f64, long S, int C, int D,
+                             const double *mu, const double *sqrt_ic, float *ftilde, float *naug, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && stat0 && stat1 && mu && sqrt_ic && ftilde && naug, "skm_tv_whiten: NULL argument");
+    SKM_REQUIRE(S > 0 && C > 0 && D > 0, "skm_tv_whiten: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = ctx->cu_count * 8;
+    SkmProfScope ps(ctx, "k_tv_whiten", st);
+    if (in_f64)
+        hipLaunchKernelGGL(k_tv_whiten<double>, dim3(blocks), dim3(256), 0, st, static_cast<const double *>(stat0),
+                           static_cast<const double *>(stat1), S, C, D, mu, sqrt_ic, ftilde, naug);
+    else
+        hipLaunchKernelGGL(k_tv_whiten<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float *>(stat0),
+                           static_cast<const float *>(stat1), S, C, D, mu, sqrt_ic, ftilde, naug);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
+extern "C" int skm_tv_prepare(void *ctx_, const double *T, int C, int D, int R, float *T32, float *G, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && T && T32 && G, "skm_tv_prepare: NULL argument");
+    SKM_REQUIRE(C > 0 && D > 0 && R > 0, "skm_tv_prepare: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        SkmProfScope ps(ctx, "k_cvt_f64_f32", st);
+        hipLaunchKernelGGL(k_cvt_f64_f32, dim3(ctx->cu_count * 8), dim3(256), 0, st, T, T32, (long)C * D * R);
+    }
+    SKM_HIP(hipGetLastError());
+    // G_c = T_c' T_c, T_c = rows [cD, (c+1)D) of T
+    GemmArgs g = skm_gemm_args(T, T, G, R, R, D, R, R, R);
+    g.transA = 1;
+    g.tile_mask = 1;
+    g.sA = g.sB = (long)D * R;
+    g.sC = (long)R * R;
+    return skm_gemm_launch(ctx, SKM_GEMM_F64_F32OUT, g, C, st, "k_gemm_gram");
+}
+
+extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, long S, int C, int D, int R,
+                            const float *T32, const float *G, int batch, double *A_aug, double *Cacc, double *e_h,
+                            double *iv_sigma, void *ws_, size_t ws_bytes, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && naug && ftilde && T32 && G && e_h && ws_, "skm_tv_estep: NULL argument");
+    SKM_REQUIRE(S > 0 && C > 0 && D > 0 && R > 0 && batch > 0, "skm_tv_estep: bad shape");
+    SKM_REQUIRE((A_aug == nullptr) == (Cacc == nullptr), "skm_tv_estep: A_aug and Cacc go together");
+    const TvWs w = tv_ws(R, S, batch);
+    if (ws_bytes < w.total) {
+        skm_set_error("skm_tv_estep: workspace too small (%zu < %zu)", ws_bytes, w.total);
+        return SKM_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = static_cast<char *>(ws_);
+    double *Mb = reinterpret_cast<double *>(ws + w.off_mb);
+    double *Linv = reinterpret_cast<double *>(ws + w.off_linv);
+    float *E = reinterpret_cast<float *>(ws + w.off_e);
+    double *Tb = reinterpret_cast<double *>(ws + w.off_tb);
+    double *aux = reinterpret_cast<double *>(ws + w.off_aux);
+    float *eh32 = reinterpret_cast<float *>(ws + w.off_eh32);
+    const long RR = (long)R * R, CD = (long)C * D;
+    const bool train = A_aug != nullptr;
+    int rc;
+
+    // aux = f~ T for every session (factor_analyser.py:88)
+    {
+        GemmArgs g = skm_gemm_args(ftilde, T32, aux, (int)S, R, (int)CD, CD, R, R);
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, g, 1, st, "k_gemm_aux"))) return rc;
+    }
+    for (long b0 = 0; b0 < S; b0 += batch) {
+        const int nb = (int)((S - b0) < batch ? (S - b0) : batch);
+        SKM_HIP(hipMemsetAsync(Mb, 0, (size_t)nb * RR * sizeof(double), st));
+        // L = sum_c N_sc G_c (identity added by the diagonal-block kernel), rows cut at their diagonal block
+        GemmArgs l = skm_gemm_args(naug + b0 * (C + 1), G, Mb, nb, R, C, C + 1, RR, RR);
+        l.tri_n = R;
+        l.tri_blk = TV_BLK;
+        l.tri_ldz = R;
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, l, R, st, "k_gemm_lbuild"))) return rc;
+        if ((rc = blocked_inverse(ctx, Mb, Linv, Tb, nb, R, 1, 1, st))) return rc;
+        {
+            SkmProfScope ps(ctx, "k_tv_finish", st);
+            hipLaunchKernelGGL(k_tv_finish, dim3(nb), dim3(256), 2 * R * sizeof(double), st, Linv, R, aux + b0 * R,
+                               e_h + b0 * R, eh32 + b0 * R, iv_sigma ? iv_sigma + b0 * R : nullptr,
+                               train ? E : nullptr);
+        }
+        SKM_HIP(hipGetLastError());
+        if (train) {
+            // A[c] += sum_s N_sc e_hh(s); row C (the ones column of naug) accumulates _R
+            GemmArgs a = skm_gemm_args(naug + b0 * (C + 1), E, A_aug, C + 1, R, nb, C + 1, RR, RR);
+            a.transA = 1;
+            a.beta = 1.0;
+            a.tri_n = R;
+            a.tri_blk = TV_BLK;
+            a.tri_ldz = R;
+            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, a, R, st, "k_gemm_aacc"))) return rc;
+        }
+    }
+    if (train) {
+        // C += e_h' f~ (factor_analyser.py:125)
+        GemmArgs c = skm_gemm_args(eh32, ftilde, Cacc, R, (int)CD, (int)S, R, CD, CD);
+        c.transA = 1;
+        c.beta = 1.0;
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, c, 1, st, "k_gemm_cacc"))) return rc;
+    }
+    return SKM_OK;
+}
+
+// M-step: T_c = (A_c^-1 C_c)' for every component; A_aug rows 0..C-1 are destroyed.
+extern "C" int skm_tv_mstep(void *ctx_, double *A_aug, const double *Cacc, int C, int D, int R, int batch,
+                            double *F_out, void *ws_, size_t ws_bytes, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && A_aug && Cacc && F_out && ws_, "skm_tv_mstep: NULL argument");
+    SKM_REQUIRE(C > 0 && D > 0 && R > 0 && batch > 0, "skm_tv_mstep: bad shape");
+    const TvWs w = tv_ws(R, 0, batch);
+    if (ws_bytes < w.total) {
+        skm_set_error("skm_tv_mstep: workspace too small (%zu < %zu)", ws_bytes, w.total);
+        return SKM_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = static_cast<char *>(ws_);
+    double *Linv = reinterpret_cast<double *>(ws + w.off_linv);
+    double *Tb = reinterpret_cast<double *>(ws + w.off_tb);
+    const long RR = (long)R * R, CD = (long)C * D;
+    int rc;
+    for (int c0 = 0; c0 < C; c0 += batch) {
+        const int nb = (C - c0) < batch ? (C - c0) : batch;
+        if ((rc = blocked_inverse(ctx, A_aug + c0 * RR, Linv, Tb, nb, R, 0, 0, st))) return rc;
+        // T_c[d][r] = sum_k C[k][cD+d] A_c^-1[k][r]
+        GemmArgs g = skm_gemm_args(Cacc + (long)c0 * D, Linv, F_out + (long)c0 * D * R, D, R, R, CD, R, R);
+        g.transA = 1;
+        g.sA = D;
+        g.sB = RR;
+        g.sC = (long)D * R;
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, g, nb, st, "k_gemm_mstep"))) return rc;
+    }
+    return SKM_OK;
+}

@@ -37,6 +37,18 @@ SIGNATURES = {
                                 _c_void_p, _c_size_t, _c_void_p]),
     "skm_bw_stats": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
                               _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "skm_gemm": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_long,
+                          _c_long, _c_long, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int, _c_long,
+                          _c_long, _c_long, _c_void_p]),
+    "skm_tv_workspace_bytes": (_c_size_t, [_c_void_p, _c_int, _c_int, _c_int, _c_long, _c_int]),
+    "skm_tv_whiten": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_int, _c_int, _c_void_p,
+                               _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "skm_tv_prepare": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "skm_tv_estep": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p,
+                              _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t,
+                              _c_void_p]),
+    "skm_tv_mstep": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p,
+                              _c_void_p, _c_size_t, _c_void_p]),
     "skm_moments_workspace_bytes": (_c_size_t, [_c_void_p, _c_int]),
     "skm_moments": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
 }
@@ -61,8 +73,6 @@ def load_library(path=None):
                            "(there is no CPU fallback)" % p)
         lib = ctypes.CDLL(p)
         for name, (res, args) in SIGNATURES.items():
-            if name.startswith("skm_tv") and not hasattr(lib, name):
-                continue
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
@@ -212,6 +222,90 @@ class HipEngine(object):
         self._check(self.lib.skm_moments(self.ctx, _c_void_p(X.data_ptr()), T, D, _c_void_p(out.data_ptr()),
                                          _c_void_p(ws), need, self._stream()))
         return out
+
+    # ------------------------------------------------------------------ total variability
+    GEMM_F32_F32, GEMM_F32_F64ACC, GEMM_F64_F64, GEMM_F64_F32OUT = 0, 1, 2, 3
+
+    def gemm(self, A, B, C=None, transA=False, transB=False, alpha=1.0, beta=0.0, kind=None):
+        """C = alpha op(A) op(B) + beta C on 2-D contiguous device tensors (float32 or float64)."""
+        torch = self.torch
+        assert A.dim() == 2 and B.dim() == 2 and A.is_contiguous() and B.is_contiguous()
+        M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+        K2, N = (B.shape[1], B.shape[0]) if transB else B.shape
+        assert K == K2, (A.shape, B.shape, transA, transB)
+        if kind is None:
+            kind = self.GEMM_F64_F64 if A.dtype == torch.float64 else self.GEMM_F32_F32
+        out_dtype = torch.float32 if kind in (self.GEMM_F32_F32, self.GEMM_F64_F32OUT) else torch.float64
+        if C is None:
+            C = torch.empty((M, N), dtype=out_dtype, device=self.device)
+            beta = 0.0
+        assert C.shape == (M, N) and C.dtype == out_dtype and C.is_contiguous()
+        self._check(self.lib.skm_gemm(self.ctx, kind, _c_void_p(A.data_ptr()), _c_void_p(B.data_ptr()),
+                                      _c_void_p(C.data_ptr()), M, N, K, A.shape[1], B.shape[1], N,
+                                      1 if transA else 0, 1 if transB else 0, float(alpha), float(beta), 1, 0, 0, 0,
+                                      self._stream()))
+        return C
+
+    def tv_whiten(self, stat0, stat1, mu_sv, invcov_sv):
+        """(ftilde float32 [S x CD], naug float32 [S x (C+1)]) from device statistics (float32 or float64)."""
+        torch = self.torch
+        S, C = stat0.shape
+        CD = stat1.shape[1]
+        D = CD // C
+        assert stat0.dtype == stat1.dtype and stat0.dtype in (torch.float32, torch.float64)
+        assert stat0.is_contiguous() and stat1.is_contiguous()
+        mu = torch.as_tensor(_as_f64(mu_sv)).to(self.device)
+        sq = torch.as_tensor(np.sqrt(_as_f64(invcov_sv))).to(self.device)
+        ft = torch.empty((S, CD), dtype=torch.float32, device=self.device)
+        naug = torch.empty((S, C + 1), dtype=torch.float32, device=self.device)
+        self._check(self.lib.skm_tv_whiten(self.ctx, _c_void_p(stat0.data_ptr()), _c_void_p(stat1.data_ptr()),
+                                           1 if stat0.dtype == torch.float64 else 0, S, C, D,
+                                           _c_void_p(mu.data_ptr()), _c_void_p(sq.data_ptr()),
+                                           _c_void_p(ft.data_ptr()), _c_void_p(naug.data_ptr()), self._stream()))
+        return ft, naug
+
+    def tv_prepare(self, T, C, D):
+        """(T32, G) for the loading matrix T (CD x R float64 device tensor)."""
+        torch = self.torch
+        CD, R = T.shape
+        assert CD == C * D and T.dtype == torch.float64 and T.is_contiguous()
+        T32 = torch.empty((CD, R), dtype=torch.float32, device=self.device)
+        G = torch.empty((C, R * R), dtype=torch.float32, device=self.device)
+        self._check(self.lib.skm_tv_prepare(self.ctx, _c_void_p(T.data_ptr()), C, D, R, _c_void_p(T32.data_ptr()),
+                                            _c_void_p(G.data_ptr()), self._stream()))
+        return T32, G
+
+    def tv_estep(self, naug, ft, T32, G, C, D, batch=256, A_aug=None, Cacc=None, uncertainty=False):
+        """E-step over the sessions of (naug, ft).  Returns (e_h, iv_sigma or None); when A_aug/Cacc are
+        given (training) the accumulators are updated in place."""
+        torch = self.torch
+        S = naug.shape[0]
+        R = T32.shape[1]
+        batch = int(max(1, min(batch, S)))
+        e_h = torch.empty((S, R), dtype=torch.float64, device=self.device)
+        sig = torch.empty((S, R), dtype=torch.float64, device=self.device) if uncertainty else None
+        need = self.lib.skm_tv_workspace_bytes(self.ctx, C, D, R, S, batch)
+        ws = self.workspace(need)
+        null = _c_void_p(None)
+        self._check(self.lib.skm_tv_estep(self.ctx, _c_void_p(naug.data_ptr()), _c_void_p(ft.data_ptr()), S, C, D, R,
+                                          _c_void_p(T32.data_ptr()), _c_void_p(G.data_ptr()), batch,
+                                          _c_void_p(A_aug.data_ptr()) if A_aug is not None else null,
+                                          _c_void_p(Cacc.data_ptr()) if Cacc is not None else null,
+                                          _c_void_p(e_h.data_ptr()),
+                                          _c_void_p(sig.data_ptr()) if sig is not None else null,
+                                          _c_void_p(ws), need, self._stream()))
+        return e_h, sig
+
+    def tv_mstep(self, A_aug, Cacc, C, D, R, batch=128):
+        """New loading matrix (CD x R float64) from the accumulators; A_aug[0:C] is destroyed."""
+        torch = self.torch
+        batch = int(max(1, min(batch, C)))
+        F = torch.empty((C * D, R), dtype=torch.float64, device=self.device)
+        need = self.lib.skm_tv_workspace_bytes(self.ctx, C, D, R, 0, batch)
+        ws = self.workspace(need)
+        self._check(self.lib.skm_tv_mstep(self.ctx, _c_void_p(A_aug.data_ptr()), _c_void_p(Cacc.data_ptr()), C, D, R,
+                                          batch, _c_void_p(F.data_ptr()), _c_void_p(ws), need, self._stream()))
+        return F
 
     # ------------------------------------------------------------------ per-kernel timing (HIP events)
     def profile(self, on):

@@ -1,0 +1,274 @@
+"""FactorAnalyser: total-variability training and i-vector extraction with the method surface of
+sidekit.FactorAnalyser (reference: sidekit/factor_analyser.py:209-808), on MI355X.
+
+The reference streams batches of sessions from an HDF5 StatServer file through a process pool
+(e_worker / e_gather, factor_analyser.py:95-128, 621-649).  Here the whitened statistics of this
+rank's sessions live in HBM for the whole training run and every EM iteration is a handful of
+batched MFMA GEMMs (csrc/skm_tv.hip).  With torch.distributed initialised the sessions are cut
+over the ranks like numpy.array_split (sidekit_mpi.py:118-123), the accumulators _A, _C, _R are
+summed with all-reduce (replaces the Reduce calls of sidekit_mpi.py:186-214) and every rank runs
+the same M-step.  PLDA (factor_analyser.py:810-910) is out of scope of this path.
+"""
+import copy
+import os
+
+import numpy as np
+
+from . import dist
+from . import engine as _engine
+from .mixture import Mixture, _has_h5py
+from .statserver import StatServer, STAT_TYPE
+
+
+def _load_stat_arrays(src, prefix=''):
+    """(modelset, segset, start, stop, stat0, stat1) with stat0/stat1 as STORED (float32 for files,
+    which is what the reference's TV code consumes, statserver.py:439-446)."""
+    if isinstance(src, StatServer):
+        return (src.modelset, src.segset, src.start, src.stop,
+                np.asarray(src.stat0).astype(np.float32), np.asarray(src.stat1).astype(np.float32))
+    a = StatServer._load_arrays(src, prefix)
+    start = np.empty(a["start"].shape, '|O')
+    stop = np.empty(a["stop"].shape, '|O')
+    start[a["start"] != -1] = a["start"][a["start"] != -1]
+    stop[a["stop"] != -1] = a["stop"][a["stop"] != -1]
+    return (a["modelset"], a["segset"], start, stop,
+            np.asarray(a["stat0"], dtype=np.float32), np.asarray(a["stat1"], dtype=np.float32))
+
+
+class FactorAnalyser(object):
+    def __init__(self, input_file_name=None, mean=None, F=None, G=None, H=None, Sigma=None, engine=None):
+        self.mean = None
+        self.F = None
+        self.G = None
+        self.H = None
+        self.Sigma = None
+        self._engine = engine
+        if input_file_name is not None:
+            fa = FactorAnalyser.read(input_file_name)
+            self.mean, self.F, self.G, self.H, self.Sigma = fa.mean, fa.F, fa.G, fa.H, fa.Sigma
+        if mean is not None:
+            self.mean = mean
+        if F is not None:
+            self.F = F
+        if G is not None:
+            self.G = G
+        if H is not None:
+            self.H = H
+        if Sigma is not None:
+            self.Sigma = Sigma
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = _engine.default_engine()
+        return self._engine
+
+    # ------------------------------------------------------------------ I/O (fa/* layout of factor_analyser.py:264-324)
+    _KEYS = (("mean", "fa/mean"), ("F", "fa/f"), ("G", "fa/g"), ("H", "fa/h"), ("Sigma", "fa/sigma"))
+
+    def write(self, output_file_name):
+        d = os.path.dirname(output_file_name)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        kind = np.zeros(5, dtype="int16")
+        data = {}
+        for i, (attr, key) in enumerate(self._KEYS):
+            v = getattr(self, attr)
+            if v is not None:
+                kind[i] = 1
+                data[key] = np.asarray(v)
+        data["fa/kind"] = kind
+        if output_file_name.endswith((".h5", ".hdf5")):
+            import h5py
+            with h5py.File(output_file_name, "w") as fh:
+                for k, v in data.items():
+                    fh.create_dataset(k, data=v, compression="gzip", fletcher32=True)
+        else:
+            with open(output_file_name, "wb") as f:
+                np.savez(f, **{k.replace("/", "__"): v for k, v in data.items()})
+
+    @staticmethod
+    def read(input_filename):
+        fa = FactorAnalyser()
+        if input_filename.endswith((".h5", ".hdf5")):
+            import h5py
+            with h5py.File(input_filename, "r") as fh:
+                kind = np.asarray(fh["fa/kind"][()])
+                for i, (attr, key) in enumerate(FactorAnalyser._KEYS):
+                    if kind[i] != 0:
+                        setattr(fa, attr, np.asarray(fh[key][()]))
+        else:
+            z = np.load(input_filename, allow_pickle=False)
+            kind = z["fa__kind"]
+            for i, (attr, key) in enumerate(FactorAnalyser._KEYS):
+                if kind[i] != 0:
+                    setattr(fa, attr, z[key.replace("/", "__")])
+        return fa
+
+    @staticmethod
+    def _ext():
+        return ".h5" if _has_h5py() else ".npz"
+
+    # ------------------------------------------------------------------ device helpers
+    def _resident_stats(self, sources, ubm, prefix=''):
+        """Whitened statistics of THIS rank's sessions in HBM: (ftilde, naug, total sessions, local slice)."""
+        eng = self.engine
+        torch = eng.torch
+        fts, naugs, total, local = [], [], 0, []
+        for src in sources:
+            _, _, _, _, s0, s1 = _load_stat_arrays(src, prefix)
+            n = s0.shape[0]
+            a, b = dist.shard_bounds(n) if dist.is_dist() else (0, n)
+            local.append((total + a, total + b))
+            total += n
+            if b > a:
+                d0 = torch.from_numpy(np.ascontiguousarray(s0[a:b])).to(eng.device)
+                d1 = torch.from_numpy(np.ascontiguousarray(s1[a:b])).to(eng.device)
+                ft, naug = eng.tv_whiten(d0, d1, ubm.get_mean_super_vector(), ubm.get_invcov_super_vector())
+                fts.append(ft)
+                naugs.append(naug)
+        if not fts:
+            return None, None, total, local
+        ft = fts[0] if len(fts) == 1 else torch.cat(fts, 0)
+        naug = naugs[0] if len(naugs) == 1 else torch.cat(naugs, 0)
+        return ft, naug, total, local
+
+    def _tv_iteration(self, ft, naug, T_dev, C, D, R, total_sessions, min_div, batch):
+        """One EM iteration on the device; returns the new loading matrix (device, float64)."""
+        eng = self.engine
+        torch = eng.torch
+        T32, G = eng.tv_prepare(T_dev, C, D)
+        A_aug = torch.zeros((C + 1, R * R), dtype=torch.float64, device=eng.device)
+        Cacc = torch.zeros((R, C * D), dtype=torch.float64, device=eng.device)
+        if ft is not None:
+            eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, A_aug=A_aug, Cacc=Cacc)
+        del G
+        dist.allreduce_sum_(A_aug)
+        dist.allreduce_sum_(Cacc)
+        r_sum = eng.to_host(A_aug[C]).reshape(R, R)
+        F_new = eng.tv_mstep(A_aug, Cacc, C, D, R)
+        if min_div:
+            # _R / nb_sessions, symmetric from its upper triangle; upper Cholesky factor
+            # (scipy.linalg.cholesky default, factor_analyser.py:661-665).  One R x R matrix per iteration.
+            up = np.triu(r_sum)
+            r_bar = (up + np.triu(r_sum, 1).T) / float(total_sessions)
+            ch = np.linalg.cholesky(r_bar).T
+            F_new = eng.gemm(F_new, torch.from_numpy(np.ascontiguousarray(ch)).to(eng.device))
+        return F_new
+
+    def _train(self, sources, ubm, tv_rank, nb_iter, min_div, tv_init, batch_size, save_init, output_file_name,
+               always_write):
+        assert (isinstance(ubm, Mixture) and ubm.validate()), "Second argument must be a proper Mixture"
+        assert (isinstance(nb_iter, int) and (0 < nb_iter)), "nb_iter must be a positive integer"
+        eng = self.engine
+        torch = eng.torch
+        C, D = ubm.distrib_nb(), ubm.dim()
+        sv_size = C * D
+        self.mean = np.zeros(sv_size, dtype=STAT_TYPE)
+        self.Sigma = np.zeros(sv_size, dtype=STAT_TYPE)
+        if tv_init is None:
+            self.F = np.random.randn(sv_size, tv_rank).astype(STAT_TYPE)   # unseeded global RNG, as the reference
+        else:
+            self.F = tv_init
+        if output_file_name is None and always_write:
+            output_file_name = "temporary_factor_analyser"
+        if save_init:
+            self.write((output_file_name or "temporary_factor_analyser") + "_init" + self._ext())
+
+        ft, naug, total, _ = self._resident_stats(sources, ubm)
+        batch = int(max(1, min(batch_size, 256)))
+        T_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(self.F, dtype=np.float64))).to(eng.device)
+        for it in range(nb_iter):
+            T_dev = self._tv_iteration(ft, naug, T_dev, C, D, tv_rank, total, min_div, batch)
+            self.F = eng.to_host(T_dev)
+            if output_file_name is not None and dist.rank() == 0:
+                if it < nb_iter - 1:
+                    self.write(output_file_name + "_it-{}".format(it) + self._ext())
+                else:
+                    self.write(output_file_name + self._ext())
+
+    # ------------------------------------------------------------------ training drivers
+    def total_variability(self, stat_server_filename, ubm, tv_rank, nb_iter=20, min_div=True, tv_init=None,
+                          batch_size=300, save_init=False, output_file_name=None, num_thread=1):
+        """TV matrix EM (factor_analyser.py:535-672).  `stat_server_filename` is a StatServer file name
+        (.npz, or .h5 when h5py is installed), a list of them, or an in-memory StatServer (its statistics
+        are rounded to float32 as a file would store them).  `num_thread` is ignored."""
+        if not isinstance(stat_server_filename, list):
+            stat_server_filename = [stat_server_filename]
+        self._train(stat_server_filename, ubm, tv_rank, nb_iter, min_div, tv_init, batch_size, save_init,
+                    output_file_name, always_write=True)
+
+    def total_variability_single(self, stat_server_filename, ubm, tv_rank, nb_iter=20, min_div=True, tv_init=None,
+                                 batch_size=300, save_init=False, output_file_name=None):
+        """Same arithmetic as total_variability (factor_analyser.py:430-533); files are only written when
+        output_file_name is given (:529-533)."""
+        self._train([stat_server_filename], ubm, tv_rank, nb_iter, min_div, tv_init, batch_size, save_init,
+                    output_file_name, always_write=False)
+
+    # ------------------------------------------------------------------ extraction
+    def _extract(self, ft, naug, ubm, batch, uncertainty):
+        eng = self.engine
+        torch = eng.torch
+        C, D = ubm.distrib_nb(), ubm.dim()
+        T_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(self.F, dtype=np.float64))).to(eng.device)
+        T32, G = eng.tv_prepare(T_dev, C, D)
+        e_h, sig = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=True)
+        return e_h, sig
+
+    def extract_ivectors(self, ubm, stat_server_filename, prefix='', batch_size=300, uncertainty=False,
+                         num_thread=1):
+        """i-vectors of every session of a StatServer file (factor_analyser.py:732-808).  Returns a
+        StatServer with stat0 = ones (S x 1) and stat1 = i-vectors (S x R) [, diagonal uncertainty S x R]."""
+        assert (isinstance(ubm, Mixture) and ubm.validate()), "Second argument must be a proper Mixture"
+        eng = self.engine
+        tv_rank = self.F.shape[1]
+        modelset, segset, start, stop, _, _ = _load_stat_arrays(stat_server_filename, prefix)
+        nb_sessions = modelset.shape[0]
+        ft, naug, total, local = self._resident_stats([stat_server_filename], ubm, prefix)
+        iv = np.zeros((nb_sessions, tv_rank), dtype=STAT_TYPE)
+        iv_sigma = np.zeros((nb_sessions, tv_rank), dtype=STAT_TYPE)
+        a, b = local[0]
+        if ft is not None:
+            e_h, sig = self._extract(ft, naug, ubm, int(max(1, min(batch_size, 256))), True)
+            iv[a:b] = eng.to_host(e_h)
+            iv_sigma[a:b] = eng.to_host(sig)
+        if dist.is_dist():
+            torch = eng.torch
+            t = torch.from_numpy(np.concatenate([iv, iv_sigma], axis=1)).to(eng.device)
+            dist.allreduce_sum_(t)                      # every row has exactly one owner
+            both = t.cpu().numpy()
+            iv, iv_sigma = both[:, :tv_rank].copy(), both[:, tv_rank:].copy()
+        iv_server = StatServer()
+        iv_server.modelset = np.asarray(modelset)       # stays as stored (bytes), factor_analyser.py:760-761
+        iv_server.segset = np.asarray(segset)
+        iv_server.start = start
+        iv_server.stop = stop
+        iv_server.stat0 = np.ones((nb_sessions, 1), dtype=STAT_TYPE)
+        iv_server.stat1 = iv
+        if uncertainty:
+            return iv_server, iv_sigma
+        return iv_server
+
+    def extract_ivectors_single(self, ubm, stat_server, uncertainty=False):
+        """In-memory variant (factor_analyser.py:674-730): whitening in float64; like the reference it
+        leaves `stat_server` whitened."""
+        assert (isinstance(stat_server, StatServer) and stat_server.validate()), \
+            "First argument must be a proper StatServer"
+        assert (isinstance(ubm, Mixture) and ubm.validate()), "Second argument must be a proper Mixture"
+        eng = self.engine
+        torch = eng.torch
+        d0 = torch.from_numpy(np.ascontiguousarray(stat_server.stat0, dtype=np.float64)).to(eng.device)
+        d1 = torch.from_numpy(np.ascontiguousarray(stat_server.stat1, dtype=np.float64)).to(eng.device)
+        ft, naug = eng.tv_whiten(d0, d1, ubm.get_mean_super_vector(), ubm.get_invcov_super_vector())
+        stat_server.whiten_stat1(ubm.get_mean_super_vector(), 1. / ubm.get_invcov_super_vector())
+        e_h, sig = self._extract(ft, naug, ubm, 256, True)
+        iv_stat_server = StatServer()
+        iv_stat_server.modelset = copy.deepcopy(stat_server.modelset)
+        iv_stat_server.segset = copy.deepcopy(stat_server.segset)
+        iv_stat_server.start = copy.deepcopy(stat_server.start)
+        iv_stat_server.stop = copy.deepcopy(stat_server.stop)
+        iv_stat_server.stat0 = np.ones((stat_server.modelset.shape[0], 1))
+        iv_stat_server.stat1 = eng.to_host(e_h)
+        if uncertainty:
+            return iv_stat_server, eng.to_host(sig)
+        return iv_stat_server

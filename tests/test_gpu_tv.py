@@ -1,0 +1,192 @@
+"""GPU parity tests of the total-variability path (GEMM building block, whitening, E-step
+accumulators, M-step, full training, i-vector extraction) against the CPU oracle and the golden
+vectors of the real reference.
+
+Tolerances: i-vectors cosine >= 0.9999 (north star) -- in practice the path is float64 wherever the
+reference is ill-conditioned (Cholesky / inverse) and float32-MFMA with float64 folding for the
+large GEMMs, so the tests also pin normwise errors (<= 2e-5 on accumulators and on F).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sidekit_ref as orc
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def min_cosine(a, b):
+    num = (a * b).sum(1)
+    den = np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1)
+    return (num / den).min()
+
+
+@pytest.fixture(scope="module")
+def sk():
+    import sidekit_amd
+    return sidekit_amd
+
+
+@pytest.fixture(scope="module")
+def eng(sk):
+    return sk.default_engine()
+
+
+def dev(eng, a, dtype=None):
+    t = eng.torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(eng.device)
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(64, 64, 64, 0, 0), (130, 70, 33, 0, 0), (33, 257, 100, 1, 0),
+                                          (200, 129, 17, 0, 1), (65, 66, 300, 1, 1), (1, 400, 1000, 0, 0)])
+@pytest.mark.parametrize("kind", ["f32", "f32acc", "f64"])
+def test_gemm(eng, M, N, K, ta, tb, kind):
+    rs = np.random.RandomState(M + N + K)
+    A = rs.randn(*((K, M) if ta else (M, K)))
+    B = rs.randn(*((N, K) if tb else (K, N)))
+    ref = (A.T if ta else A).dot(B.T if tb else B)
+    torch = eng.torch
+    if kind == "f64":
+        C = eng.gemm(dev(eng, A), dev(eng, B), transA=ta, transB=tb)
+        tol = 1e-13
+    else:
+        k = eng.GEMM_F32_F32 if kind == "f32" else eng.GEMM_F32_F64ACC
+        C = eng.gemm(dev(eng, A, torch.float32), dev(eng, B, torch.float32), transA=ta, transB=tb, kind=k)
+        ref = (A.astype(np.float32).astype(np.float64).T if ta else A.astype(np.float32).astype(np.float64)).dot(
+            B.astype(np.float32).astype(np.float64).T if tb else B.astype(np.float32).astype(np.float64))
+        tol = 2e-6
+    assert rel(eng.to_host(C), ref) < tol
+
+
+def test_gemm_alpha_beta_asymmetric(eng):
+    # asymmetric operands catch a transposed C write; beta path accumulates
+    A = np.arange(70 * 40, dtype=np.float64).reshape(70, 40) / 100.0
+    B = np.cos(np.arange(40 * 90, dtype=np.float64)).reshape(40, 90)
+    C0 = np.sin(np.arange(70 * 90, dtype=np.float64)).reshape(70, 90)
+    C = dev(eng, C0.copy())
+    eng.gemm(dev(eng, A), dev(eng, B), C=C, alpha=-0.5, beta=2.0)
+    assert rel(eng.to_host(C), -0.5 * A.dot(B) + 2.0 * C0) < 1e-13
+
+
+def _ubm(sk, g):
+    ubm = sk.Mixture()
+    ubm.w, ubm.mu, ubm.invcov = g["w"].copy(), g["mu"].copy(), g["invcov"].copy()
+    ubm.cov_var_ctl = 1.0 / ubm.invcov
+    ubm._compute_all()
+    return ubm
+
+
+def test_whiten_bit_exact_float32(eng):
+    g = golden("tv.npz")
+    gmm = orc.GMM(g["w"], g["mu"], g["invcov"])
+    ft, naug = eng.tv_whiten(dev(eng, g["stat0_f32"][:9]), dev(eng, g["stat1_f32"][:9]), gmm.mu.flatten(),
+                             gmm.invcov.flatten())
+    np.testing.assert_array_equal(eng.to_host(ft), g["eob_whitened"])
+    na = eng.to_host(naug)
+    np.testing.assert_array_equal(na[:, :-1], g["stat0_f32"][:9])
+    assert np.all(na[:, -1] == 1.0)
+
+
+def _accumulators(eng, gmm, s0, s1, Fm, batch):
+    C, D = gmm.C, gmm.D
+    R = Fm.shape[1]
+    torch = eng.torch
+    ft, naug = eng.tv_whiten(dev(eng, s0), dev(eng, s1), gmm.mu.flatten(), gmm.invcov.flatten())
+    T32, G = eng.tv_prepare(dev(eng, Fm), C, D)
+    A_aug = torch.zeros((C + 1, R * R), dtype=torch.float64, device=eng.device)
+    Cacc = torch.zeros((R, C * D), dtype=torch.float64, device=eng.device)
+    e_h, sig = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, A_aug=A_aug, Cacc=Cacc, uncertainty=True)
+    return eng.to_host(A_aug).reshape(C + 1, R, R), eng.to_host(Cacc), eng.to_host(e_h), eng.to_host(sig), A_aug, Cacc
+
+
+def _upper_packed(A_full):
+    iu = np.triu_indices(A_full.shape[-1])
+    return A_full[..., iu[0], iu[1]]
+
+
+@pytest.mark.parametrize("case", ["golden", "r100", "r400"])
+def test_estep_accumulators_and_mstep(eng, case):
+    if case == "golden":
+        g = golden("tv.npz")
+        gmm = orc.GMM(g["w"], g["mu"], g["invcov"])
+        s0, s1, Fm, batch = g["stat0_f32"], g["stat1_f32"], g["tv_init"], 7
+    else:
+        C, D, R, S = (24, 12, 100, 90) if case == "r100" else (40, 8, 400, 40)
+        gmm = orc.random_gmm(C, D, seed=41)
+        sess = [orc.synth_frames(int(n), dim=D, clusters=8, seed=500 + i).astype(np.float64)
+                for i, n in enumerate(np.random.RandomState(3).randint(200, 3000, size=S))]
+        s0, s1 = orc.accumulate_stat(gmm, sess)
+        s0, s1 = s0.astype(np.float32), s1.astype(np.float32)
+        Fm = 0.1 * np.random.RandomState(7).randn(C * D, R)
+        batch = 32
+    C, D = gmm.C, gmm.D
+    R = Fm.shape[1]
+    A, Cc, e_h, sig, A_dev, C_dev = _accumulators(eng, gmm, s0, s1, Fm, batch)
+    rA, rC, rR = orc.tv_accumulate(s0, s1, gmm, Fm, batch_size=300)
+    rR = rR * s0.shape[0]
+    assert rel(_upper_packed(A[:C]), rA) < 2e-5
+    assert rel(Cc, rC) < 2e-5
+    assert rel(_upper_packed(A[C]), rR) < 2e-5
+    iv, iv_sigma = orc.extract_ivectors(s0, s1, gmm, Fm)
+    assert rel(e_h, iv) < 2e-5
+    assert rel(sig, iv_sigma) < 2e-5
+    assert min_cosine(e_h, iv) > 0.9999
+    # M-step from the DEVICE accumulators against the oracle's M-step from ITS accumulators
+    Fn = eng.to_host(eng.tv_mstep(A_dev, C_dev, C, D, R))
+    rF = orc.tv_mstep(rA, rC, rR / s0.shape[0], D, min_div=False)
+    assert rel(Fn, rF) < 1e-4
+
+
+def test_total_variability_dropin_vs_reference_golden(sk, tmp_path):
+    g = golden("tv.npz")
+    ubm = _ubm(sk, g)
+    S = g["stat0_f32"].shape[0]
+    ss = sk.StatServer()
+    ss.modelset = np.array(["spk%d" % (i % 5) for i in range(S)])
+    ss.segset = np.array(["s%03d" % i for i in range(S)])
+    ss.start = np.empty(S, "|O")
+    ss.stop = np.empty(S, "|O")
+    ss.stat0 = g["stat0_f32"].astype(np.float64)
+    ss.stat1 = g["stat1_f32"].astype(np.float64)
+    stat_file = str(tmp_path / "stat.npz")
+    ss.write(stat_file)
+
+    fa = sk.FactorAnalyser()
+    fa.total_variability_single(stat_file, ubm, 6, nb_iter=1, min_div=True, tv_init=g["tv_init"].copy(), batch_size=7)
+    assert rel(fa.F, g["F_it1"]) < 1e-4
+    fa = sk.FactorAnalyser()
+    fa.total_variability(stat_file, ubm, 6, nb_iter=3, min_div=True, tv_init=g["tv_init"].copy(), batch_size=7,
+                         output_file_name=str(tmp_path / "tv"), num_thread=1)
+    assert rel(fa.F, g["F_it3_pool"]) < 1e-4
+    assert np.all(fa.mean == 0) and np.all(fa.Sigma == 0) and fa.mean.shape == g["fa_mean"].shape
+    assert os.path.exists(str(tmp_path / "tv_it-0") + sk.FactorAnalyser._ext())
+    back = sk.FactorAnalyser(str(tmp_path / "tv") + sk.FactorAnalyser._ext())
+    np.testing.assert_array_equal(back.F, fa.F)
+    fa2 = sk.FactorAnalyser()
+    fa2.total_variability_single(stat_file, ubm, 6, nb_iter=2, min_div=False, tv_init=g["tv_init"].copy(),
+                                 batch_size=7)
+    assert rel(fa2.F, g["F_it2_nomindiv"]) < 1e-4
+
+    # extraction with the REFERENCE's trained matrix: isolates extraction parity
+    fa3 = sk.FactorAnalyser(F=g["F_it3_pool"].copy())
+    ivs, sig = fa3.extract_ivectors(ubm, stat_file, prefix="", batch_size=7, uncertainty=True, num_thread=1)
+    assert ivs.stat0.shape == (S, 1) and np.all(ivs.stat0 == 1.0)
+    assert min_cosine(ivs.stat1, g["iv"]) > 0.9999
+    assert rel(ivs.stat1, g["iv"]) < 2e-5
+    assert rel(sig, g["iv_sigma"]) < 2e-5
+    ss2 = sk.StatServer(stat_file)
+    ivs2, sig2 = fa3.extract_ivectors_single(ubm, ss2, uncertainty=True)
+    assert min_cosine(ivs2.stat1, g["iv_single"]) > 0.9999
+    assert rel(ivs2.stat1, g["iv_single"]) < 2e-5
+    assert rel(sig2, g["iv_sigma_single"]) < 2e-5
