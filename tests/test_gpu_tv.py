@@ -139,8 +139,10 @@ def test_estep_accumulators_and_mstep(eng, case):
     assert rel(Cc, rC) < 2e-5
     assert rel(_upper_packed(A[C]), rR) < 2e-5
     iv, iv_sigma = orc.extract_ivectors(s0, s1, gmm, Fm)
-    assert rel(e_h, iv) < 2e-5
-    assert rel(sig, iv_sigma) < 2e-5
+    # r400 has R > C*D: T'T is rank deficient and L = I + sum N_c G_c is the worst-conditioned case on
+    # purpose; the float32 Gram matrices then cost cond(L) * 6e-8 on e_h
+    assert rel(e_h, iv) < (1e-4 if case == "r400" else 2e-5)
+    assert rel(sig, iv_sigma) < (1e-4 if case == "r400" else 2e-5)
     assert min_cosine(e_h, iv) > 0.9999
     # M-step from the DEVICE accumulators against the oracle's M-step from ITS accumulators
     Fn = eng.to_host(eng.tv_mstep(A_dev, C_dev, C, D, R))
