@@ -18,6 +18,7 @@ Also reported on the same JSON line (rank 0, N=1 detail):
   cpu_baseline  the NumPy float64 oracle (a port of the reference's call sequence) on a bounded
                 sample of the same workload, host cores stated
   bw_stats      Baum-Welch N/F accumulation (configs[3] at reduced session count), frames/s
+  tv            TV training iteration and i-vector extraction (configs[4] at reduced session count)
 """
 import argparse
 import json
@@ -107,6 +108,7 @@ def main():
     ap.add_argument("--frames", type=int, default=10_000_000, help="frames per GPU")
     ap.add_argument("--comps", type=int, default=512)
     ap.add_argument("--dim", type=int, default=60)
+    ap.add_argument("--tv-sessions", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (BW stats)")
     args = ap.parse_args()
@@ -219,6 +221,56 @@ def main():
                                            "avg_launch_ms": t_bw},
                               "path_frac_of_mfma_peak": 6.0 * D * Cb * S * L / dtb / 1e12 / PEAK_F32_MFMA_TFLOPS}
         del s0, s1
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        # ---- TV training iteration + i-vector extraction (BASELINE configs[4], fewer sessions): R=400, C=2048
+        del X
+        torch.cuda.empty_cache()
+        Ct, R, St = 2048, 400, args.tv_sessions
+        ubm_t = random_ubm(sk, Ct, D, seed=11)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(4321)
+        post = torch.softmax(2.0 * torch.randn(St, Ct, generator=gen, device=dev), dim=1)
+        stat0 = (2000.0 * post).to(torch.float32)
+        mu_sv = torch.as_tensor(ubm_t.get_mean_super_vector(), device=dev)
+        sd_sv = torch.as_tensor(1.0 / np.sqrt(ubm_t.get_invcov_super_vector()), device=dev)
+        n_rep = stat0.repeat_interleave(D, dim=1).to(torch.float64)
+        stat1 = (n_rep * mu_sv + torch.sqrt(n_rep) * sd_sv *
+                 torch.randn(St, Ct * D, generator=gen, device=dev, dtype=torch.float64)).to(torch.float32)
+        del n_rep, post
+        ft, naug = eng.tv_whiten(stat0, stat1, ubm_t.get_mean_super_vector(), ubm_t.get_invcov_super_vector())
+        del stat1
+        fa = sk.FactorAnalyser()
+        T_dev = torch.as_tensor(0.1 * np.random.RandomState(7).randn(Ct * D, R), device=dev)
+        T_dev = fa._tv_iteration(ft, naug, T_dev, Ct, D, R, St, True, 256)       # warm-up iteration
+        torch.cuda.synchronize()
+        eng.profile(True)
+        t0 = time.perf_counter()
+        T_dev = fa._tv_iteration(ft, naug, T_dev, Ct, D, R, St, True, 256)
+        torch.cuda.synchronize()
+        dt_tv = time.perf_counter() - t0
+        prof_tv = eng.profile_read()
+        T32, G = eng.tv_prepare(T_dev, Ct, D)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e_h, _ = eng.tv_estep(naug, ft, T32, G, Ct, D, batch=256, uncertainty=True)
+        torch.cuda.synchronize()
+        dt_iv = time.perf_counter() - t0
+        prof_iv = eng.profile_read()
+        eng.profile(False)
+        flop_train, flop_iv = 9.18e8, 4.5e8          # algorithmic flop per session
+        result["tv"] = {
+            "workload": "TV EM iteration (E-step + M-step + min-div) and extract_ivectors, R=%d, C=%d, D=%d, "
+                        "%d synthetic sessions" % (R, Ct, D, St),
+            "train_sessions_per_s": St / dt_tv, "train_s_per_iteration": dt_tv,
+            "train_algorithmic_tflops": flop_train * St / dt_tv / 1e12,
+            "ivectors_per_s": St / dt_iv,
+            "extract_algorithmic_tflops": flop_iv * St / dt_iv / 1e12,
+            "train_kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof_tv.items())},
+            "extract_kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof_iv.items())},
+            "note": "M-step cost (2048 R x R inverses) is independent of the session count and is amortised "
+                    "over 50k sessions in configs[4]; it is included in train_s_per_iteration here"}
+        del ft, naug, T32, G, e_h, T_dev
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(C, D)

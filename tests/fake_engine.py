@@ -1,0 +1,98 @@
+"""TEST DOUBLE (never shipped, never imported by the package): an engine with the interface of
+speaker-recognition_amd.engine.HipEngine whose arithmetic is the CPU oracle.  It exists so that the
+host-side logic of the drop-in classes -- sharding over ranks, all-reduce of packed statistics,
+M-step, file products -- can be exercised on CPU with the gloo backend (world_size 2), where no
+GPU and therefore no HIP kernel is available."""
+import numpy as np
+import torch
+
+from oracle import sidekit_ref as orc
+
+
+class _Packed(object):
+    def __init__(self, w, mu, invcov):
+        self.gmm = orc.GMM(w, mu, invcov)
+        self.C, self.D = self.gmm.C, self.gmm.D
+
+
+class OracleEngine(object):
+    def __init__(self):
+        self.torch = torch
+        self.device = torch.device("cpu")
+
+    def upload_frames(self, x):
+        if isinstance(x, torch.Tensor):
+            return x.to(torch.float32).contiguous()
+        a = np.asarray(x, dtype=np.float32)
+        if a.ndim == 1:
+            a = a[:, None]
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    def pack(self, w, mu, invcov):
+        return _Packed(w, mu, invcov)
+
+    def estep(self, X, gmm, out=None, accumulate=False):
+        N, F, S, llk = orc.expectation(gmm.gmm, X.numpy().astype(np.float64))
+        flat = torch.from_numpy(np.concatenate([N, F.ravel(), S.ravel(), [llk]]))
+        if out is not None and accumulate:
+            out += flat
+            return out
+        return flat
+
+    def moments(self, X):
+        x = X.numpy().astype(np.float64)
+        return torch.from_numpy(np.concatenate([x.sum(0), (x ** 2).sum(0)]))
+
+    def bw_stats(self, X, seg_off, gmm, stat0=None, stat1=None):
+        x = X.numpy().astype(np.float64)
+        off = np.asarray(seg_off)
+        s0, s1 = orc.accumulate_stat(gmm.gmm, [x[off[i]:off[i + 1]] for i in range(len(off) - 1)])
+        return torch.from_numpy(s0), torch.from_numpy(s1)
+
+    def to_host(self, t):
+        return t.detach().cpu().numpy()
+
+    # ---- TV (dense float64 restatement of csrc/skm_tv.hip's data flow)
+    def tv_whiten(self, stat0, stat1, mu_sv, invcov_sv):
+        s0 = stat0.numpy().copy()
+        s1 = stat1.numpy().copy()
+        C = s0.shape[1]
+        D = s1.shape[1] // C
+        idx = np.repeat(np.arange(C), D)
+        s1 -= s0[:, idx] * np.asarray(mu_sv)
+        s1 *= np.sqrt(np.asarray(invcov_sv))
+        naug = np.concatenate([s0, np.ones((s0.shape[0], 1), dtype=s0.dtype)], axis=1).astype(np.float32)
+        return torch.from_numpy(s1.astype(np.float32)), torch.from_numpy(naug)
+
+    def tv_prepare(self, T, C, D):
+        return T.clone(), None
+
+    def tv_estep(self, naug, ft, T32, G, C, D, batch=256, A_aug=None, Cacc=None, uncertainty=False):
+        Fm = T32.numpy()
+        R = Fm.shape[1]
+        n = naug.numpy().astype(np.float64)
+        f = ft.numpy().astype(np.float64)
+        idx = np.repeat(np.arange(C), D)
+        e_h = np.zeros((n.shape[0], R))
+        sig = np.zeros((n.shape[0], R))
+        for s in range(n.shape[0]):
+            inv = np.linalg.inv(np.eye(R) + (Fm.T * n[s, idx]).dot(Fm))
+            e_h[s] = Fm.T.dot(f[s]).dot(inv)
+            e_hh = inv + np.outer(e_h[s], e_h[s])
+            sig[s] = np.diag(e_hh)
+            if A_aug is not None:
+                A_aug += torch.from_numpy(np.outer(n[s], e_hh.ravel()))
+        if Cacc is not None:
+            Cacc += torch.from_numpy(e_h.T.dot(f))
+        return torch.from_numpy(e_h), (torch.from_numpy(sig) if uncertainty else None)
+
+    def tv_mstep(self, A_aug, Cacc, C, D, R, batch=128):
+        A = A_aug.numpy().reshape(C + 1, R, R)
+        Cc = Cacc.numpy()
+        Fm = np.zeros((C * D, R))
+        for c in range(C):
+            Fm[c * D:(c + 1) * D] = np.linalg.solve(A[c], Cc[:, c * D:(c + 1) * D]).T
+        return torch.from_numpy(Fm)
+
+    def gemm(self, A, B, **kw):
+        return torch.from_numpy(A.numpy().dot(B.numpy()))

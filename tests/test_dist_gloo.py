@@ -1,0 +1,150 @@
+"""Multi-rank host logic on CPU: world_size-2 gloo runs of the drop-in classes with the oracle-backed
+test double (tests/fake_engine.py) in place of the HIP engine.  Checks that sharding frames / sessions
+over ranks + all-reduce of the packed statistics gives every rank the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sidekit_amd as sk
+        from fake_engine import OracleEngine
+        from oracle import sidekit_ref as orc
+        eng = OracleEngine()
+        out = {}
+        assert sk.dist.world_size() == world and sk.dist.rank() == rank
+        # shard_bounds == numpy.array_split
+        for n in (0, 1, 7, 10, 11):
+            parts = np.array_split(np.arange(n), world)
+            a, b = sk.dist.shard_bounds(n)
+            assert list(range(a, b)) == list(parts[rank]), (n, a, b)
+
+        # ---- EM_split: frames sharded by rows, one all-reduce per iteration
+        g = np.load(os.path.join(GOLDEN, "em_split.npz"))
+        chunks = {"f%d" % i: g["chunk%d" % i] for i in range(4)}
+        ubm = sk.Mixture(engine=eng)
+        llk = ubm.EM_split(features_server=sk.FeaturesServer(features=chunks), feature_list=list(chunks), distrib_nb=8)
+        out["em_llk"] = np.abs(np.array(llk) - g["llk"]).max() / np.abs(g["llk"]).max()
+        out["em_mu"] = np.abs(ubm.mu - g["mu"]).max() / np.abs(g["mu"]).max()
+        out["em_w"] = np.abs(ubm.w - g["w"]).max()
+
+        # ---- EM_uniform
+        gu = np.load(os.path.join(GOLDEN, "em_uniform.npz"))
+        u2 = sk.Mixture(engine=eng)
+        l2 = u2.EM_uniform(gu["cep"], 4)
+        out["emu_llk"] = np.abs(np.array(l2) - gu["llk"]).max() / np.abs(gu["llk"]).max()
+
+        # ---- accumulate_stat: sessions sharded, rows summed back
+        ga = np.load(os.path.join(GOLDEN, "accumulate_stat.npz"))
+        off = np.concatenate([[0], np.cumsum(ga["lens"])])
+        names = ["s%03d" % i for i in range(len(ga["lens"]))]
+        fs = sk.FeaturesServer(features={n: ga["frames"][off[i]:off[i + 1]] for i, n in enumerate(names)})
+        ub = sk.Mixture(engine=eng)
+        ub.w, ub.mu, ub.invcov = ga["w"].copy(), ga["mu"].copy(), ga["invcov"].copy()
+        ub.cov_var_ctl = 1.0 / ub.invcov
+        ub._compute_all()
+        ss = sk.StatServer(sk.IdMap().set(["m"] * len(names), names), ubm=ub, engine=eng)
+        ss.accumulate_stat(ubm=ub, feature_server=fs, seg_indices=range(len(names)))
+        out["bw0"] = np.abs(ss.stat0 - ga["stat0"]).max() / np.abs(ga["stat0"]).max()
+        out["bw1"] = np.abs(ss.stat1 - ga["stat1"]).max() / np.abs(ga["stat1"]).max()
+
+        # ---- TV training + extraction: sessions sharded, accumulators all-reduced
+        gt = np.load(os.path.join(GOLDEN, "tv.npz"))
+        S = gt["stat0_f32"].shape[0]
+        st = sk.StatServer(engine=eng)
+        st.modelset = np.array(["m%d" % (i % 3) for i in range(S)])
+        st.segset = np.array(["s%03d" % i for i in range(S)])
+        st.start = np.empty(S, "|O")
+        st.stop = np.empty(S, "|O")
+        st.stat0 = gt["stat0_f32"].astype(np.float64)
+        st.stat1 = gt["stat1_f32"].astype(np.float64)
+        stat_file = os.path.join(tmp, "stat_r%d.npz" % rank)
+        st.write(stat_file)
+        ut = sk.Mixture(engine=eng)
+        ut.w, ut.mu, ut.invcov = gt["w"].copy(), gt["mu"].copy(), gt["invcov"].copy()
+        ut.cov_var_ctl = 1.0 / ut.invcov
+        ut._compute_all()
+        fa = sk.FactorAnalyser(engine=eng)
+        fa.total_variability(stat_file, ut, 6, nb_iter=3, min_div=True, tv_init=gt["tv_init"].copy(), batch_size=7,
+                             output_file_name=os.path.join(tmp, "tv_r%d" % rank))
+        out["tv_F"] = np.abs(fa.F - gt["F_it3_pool"]).max() / np.abs(gt["F_it3_pool"]).max()
+        fa.F = gt["F_it3_pool"].copy()
+        ivs = fa.extract_ivectors(ut, stat_file, batch_size=7)
+        out["iv"] = np.abs(ivs.stat1 - gt["iv"]).max() / np.abs(gt["iv"]).max()
+        q.put((rank, out))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_gloo_matches_single_process(tmp_path):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        r = res[rank]
+        # float32 upload of the frames bounds the EM figures; everything after is float64
+        assert r["em_llk"] < 1e-5 and r["em_mu"] < 1e-5 and r["em_w"] < 1e-5, r
+        assert r["emu_llk"] < 1e-5, r
+        assert r["bw0"] < 1e-5 and r["bw1"] < 1e-5, r
+        assert r["tv_F"] < 1e-5 and r["iv"] < 1e-5, r
+    # both ranks hold the same model
+    assert abs(res[0]["em_mu"] - res[1]["em_mu"]) < 1e-12
+
+
+def test_library_exports_every_declared_symbol():
+    """No GPU needed: the C-ABI library loads and exports everything include/skm.h declares."""
+    import re
+    sys.path.insert(0, ROOT)
+    import sidekit_amd as sk
+    lib = sk.load_library()
+    hdr = open(os.path.join(ROOT, "include", "skm.h")).read()
+    names = set(re.findall(r"\b(skm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 18
+    for n in sorted(names):
+        assert hasattr(lib, n), "libskm.so does not export %s" % n
+    assert lib.skm_version() >= 100
+    assert lib.skm_gmm_packed_bytes(512, 60) == (512 // 32) * (15 * 256 + 32) * 4
+    assert set(sk.package.engine.SIGNATURES) == names
+
+
+def test_engine_refuses_without_gpu():
+    sys.path.insert(0, ROOT)
+    import sidekit_amd as sk
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(sk.SkmError):
+        sk.HipEngine()
+    with pytest.raises(sk.SkmError):
+        sk.Mixture().EM_uniform(np.zeros((100, 4)), 2)
