@@ -23,6 +23,7 @@
 #include "skm_common.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // error handling
@@ -228,6 +229,64 @@ __device__ __forceinline__ void gemm_logits(f32x16 (&lg)[NCT], const float *xs_r
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Row logsumexp of a logits tile: frames sit in the 16 accumulator registers (x2 lane halves), components
+// on the 32 lanes of a half.  "Transposed" butterfly on (max, sum-of-exp2) pairs: each exchange step
+// halves the number of live registers, so 16 registers x 32 lanes cost 24 cross-lane moves instead of
+// 160.  On return lane (c, h) holds the pair of frame acc_row((c >> 1) & 15, h), reduced over the 32
+// components of the half (and the NCT tiles); lanes c and c^1 hold the same pair.
+// ------------------------------------------------------------------------------------------------
+template <int MASK>
+__device__ __forceinline__ float xor_lane(float v)
+{
+    // ds_swizzle bit mode: lane' = ((lane & 0x1f) | 0) ^ MASK inside each group of 32 lanes
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (MASK << 10) | 0x1F));
+}
+
+template <int N, int MASK>
+__device__ __forceinline__ void lse_halve(float (&m)[16], float (&s)[16], bool upper)
+{
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+        const float km = upper ? m[j + N / 2] : m[j], ks = upper ? s[j + N / 2] : s[j];
+        const float sm = upper ? m[j] : m[j + N / 2], ss = upper ? s[j] : s[j + N / 2];
+        const float rm = xor_lane<MASK>(sm), rs = xor_lane<MASK>(ss);
+        const float nm = fmaxf(km, rm);
+        m[j] = nm;
+        s[j] = ks * __builtin_amdgcn_exp2f(km - nm) + rs * __builtin_amdgcn_exp2f(rm - nm);
+    }
+}
+
+template <int NCT>
+__device__ __forceinline__ void wave_lse_reduce(const f32x16 (&lg)[NCT], int c, float &m_out, float &s_out)
+{
+    float m[16], s[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float mm = lg[0][r];
+#pragma unroll
+        for (int ct = 1; ct < NCT; ++ct) mm = fmaxf(mm, lg[ct][r]);
+        float ss = 0.f;
+        if (NCT == 1) {
+            ss = 1.f;
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) ss += __builtin_amdgcn_exp2f(lg[ct][r] - mm);
+        }
+        m[r] = mm;
+        s[r] = ss;
+    }
+    lse_halve<16, 16>(m, s, (c & 16) != 0);
+    lse_halve<8, 8>(m, s, (c & 8) != 0);
+    lse_halve<4, 4>(m, s, (c & 4) != 0);
+    lse_halve<2, 2>(m, s, (c & 2) != 0);
+    const float rm = xor_lane<1>(m[0]), rs = xor_lane<1>(s[0]);
+    const float nm = fmaxf(m[0], rm);
+    m_out = nm;
+    s_out = s[0] * __builtin_amdgcn_exp2f(m[0] - nm) + rs * __builtin_amdgcn_exp2f(rm - nm);
+}
+
 // ------------------------------------------------------------------------------------------------
 // sweep 1: per (component block, frame) partial max / sum of exp2
 // ------------------------------------------------------------------------------------------------
@@ -288,27 +347,11 @@ __global__ __launch_bounds__(512, 2) void k_lse_partial(LseArgs a)
 
         gemm_logits<NCT>(lg, xs + c * g.XS, h, Wl4, g);
 
-        // Row (= frame) reductions across the 32 component lanes of each half and the NCT tiles.
-        float mym = 0.f, mys = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float m = lg[0][r];
-#pragma unroll
-            for (int ct = 1; ct < NCT; ++ct) m = fmaxf(m, lg[ct][r]);
-#pragma unroll
-            for (int msk = 1; msk < 32; msk <<= 1) m = fmaxf(m, __shfl_xor(m, msk));
-            float s = 0.f;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) s += __builtin_amdgcn_exp2f(lg[ct][r] - m);
-#pragma unroll
-            for (int msk = 1; msk < 32; msk <<= 1) s += __shfl_xor(s, msk);
-            if (c == r) {
-                mym = m;
-                mys = s;
-            }
-        }
-        if (c < 16) {
-            const int frame = acc_row(c, h);
+        // Row (= frame) logsumexp over the 32 component lanes of each half and the NCT tiles.
+        float mym, mys;
+        wave_lse_reduce<NCT>(lg, c, mym, mys);
+        if ((c & 1) == 0) {
+            const int frame = acc_row((c >> 1) & 15, h);
             if (frame < nvalid) {
                 pm[t0 + frame] = mym;
                 ps[t0 + frame] = mys;
@@ -365,6 +408,43 @@ struct StatsArgs {
     double *stat1;
 };
 
+// GEMM 2: acc[ct][jf] += gamma' [x | x^2].  Register r of the logits tile holds gamma[frame acc_row(r,h)]
+// [comp c] = the A operand of the k-pair {acc_row(r,0), acc_row(r,1)}; B = the staged frame row (32
+// feature columns per tile), x^2 squared on the fly.  The B operands of step r+1 are fetched while the
+// MFMAs of step r issue; the scheduling barrier keeps the compiler from hoisting all 16 steps' loads
+// (which costs more registers than the kernel has).
+template <int NJT, int NCT, bool WITH_S>
+__device__ __forceinline__ void gemm_stats(f32x16 (&acc)[NCT][NJT * (WITH_S ? 2 : 1)], const f32x16 (&lg)[NCT],
+                                           const float *xcol, int XS)
+{
+    float bn[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) bn[jt] = xcol[jt * 32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float b[NJT];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) b[jt] = bn[jt];
+        if (r < 15) {
+            const float *xrow = xcol + acc_row(r + 1, 0) * XS;
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) bn[jt] = xrow[jt * 32];
+        }
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct][jt] = SKM_MFMA32(lg[ct][r], b[jt], acc[ct][jt]);
+            if (WITH_S) {
+                const float b2 = b[jt] * b[jt];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct][NJT * (WITH_S ? 1 : 0) + jt] = SKM_MFMA32(lg[ct][r], b2, acc[ct][NJT * (WITH_S ? 1 : 0) + jt]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // One 32-frame tile: stage, logits - lse, gamma, statistics GEMM into acc.
 template <int NJT, int NCT, bool WITH_S>
 __device__ __forceinline__ void stats_tile(f32x16 (&acc)[NCT][NJT * (WITH_S ? 2 : 1)], float *xs, float *ls,
@@ -396,25 +476,7 @@ __device__ __forceinline__ void stats_tile(f32x16 (&acc)[NCT][NJT * (WITH_S ? 2 
 #pragma unroll
         for (int r = 0; r < 16; ++r) lg[ct][r] = __builtin_amdgcn_exp2f(lg[ct][r]);
 
-    // GEMM 2: register r of the logits tile holds gamma[frame acc_row(r,h)][comp c] = A operand
-    // of the k-pair {acc_row(r,0), acc_row(r,1)}; B = staged frame row, 32 feature columns per tile.
-    const float *xcol = xs + 4 * h * g.XS + c;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float *xrow = xcol + acc_row(r, 0) * g.XS;
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            const float b = xrow[jt * 32];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[ct][jt] = SKM_MFMA32(lg[ct][r], b, acc[ct][jt]);
-            if (WITH_S) {
-                const float b2 = b * b;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-                    acc[ct][NJT * (WITH_S ? 1 : 0) + jt] = SKM_MFMA32(lg[ct][r], b2, acc[ct][NJT * (WITH_S ? 1 : 0) + jt]);
-            }
-        }
-    }
+    gemm_stats<NJT, NCT, WITH_S>(acc, lg, xs + 4 * h * g.XS + c, g.XS);
     wave_lds_fence();  // every read of xs retired (in order) before the next tile is staged
 }
 
@@ -536,6 +598,194 @@ __global__ __launch_bounds__(512, 2) void k_stats(StatsArgs a)
             }
             flush_session<NCT, NF>(acc, a.stat0 + s * (long)C, a.stat1 + s * (long)C * D, cb, C, D, lane);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-sweep E-step for C <= 512 (7..16 component tiles): one workgroup covers ALL components, so the
+// row logsumexp is finished inside the workgroup and the logits are never recomputed (124 instead of 184
+// MFMAs per 32x32 logits tile).  Wave w owns component tiles 2w, 2w+1 (W streamed from L2 in fragment
+// order, 1 KB per wave-instruction); all waves share one staged frame tile (three LDS buffers, so one
+// workgroup barrier per tile orders both the staging and the exchange of the per-wave partials).
+// ------------------------------------------------------------------------------------------------
+struct FusedArgs {
+    const float *X;
+    long T;
+    TileGeom g;
+    const float *wp;
+    const float *kc;
+    double *slabs;     // [n_blocks][NWV] slabs of [64][NF*32] f64 (zeroed by the host)
+    double *llk_part;  // [n_blocks]
+};
+
+template <int NJT>
+__global__ __launch_bounds__(512, 2) void k_estep_fused(FusedArgs a)
+{
+    constexpr int NCT = 2, NF = 2 * NJT, NFW = NF * 32, PRE = 8;  // PRE floats staged per thread (>= 256 threads, D <= 63)
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, NWV = nthr >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const TileGeom g = a.g;
+    const int tile_floats = 32 * g.XS;
+
+    float *xs = smem;                                // [3][32][XS]
+    float *partm = xs + 3 * tile_floats;             // [2][NWV][32]
+    float *parts = partm + 2 * NWV * 32;             // [2][NWV][32]
+    float *ls = parts + 2 * NWV * 32 + wave * 32;    // wave-private lse[32]
+
+    // constant padding columns (ones column at D) of the three buffers
+    {
+        const int padw = g.XS - g.D;
+        for (int i = tid; i < 3 * 32 * padw; i += nthr) {
+            const int row = i / padw, col = g.D + (i - row * padw);
+            xs[row * g.XS + col] = (col == g.D) ? 1.0f : 0.0f;
+        }
+    }
+    float kcv[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) kcv[ct] = a.kc[(wave * NCT + ct) * 32 + c];
+    const f32x4 *Wg4 = reinterpret_cast<const f32x4 *>(a.wp) + (long)(wave * NCT) * g.NG * 64 + lane;
+
+    f32x16 acc[NCT][NF];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int jf = 0; jf < NF; ++jf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
+
+    const long tiles = (a.T + 31) >> 5;
+    const long ta = tiles * blockIdx.x / gridDim.x, tb = tiles * (blockIdx.x + 1) / gridDim.x;
+    double *slab_lane = a.slabs + ((long)blockIdx.x * NWV + wave) * (long)(NCT * 32 * NFW) + (4 * h) * NFW + c;
+    double llk_lane = 0.0;
+
+    // cooperative staging: element e of the tile's contiguous span -> (row, col); up to PRE floats per thread
+    const int n_el = g.vec4 ? 32 * (g.D >> 2) : 32 * g.D;   // float4 or float elements
+    float pre[PRE];
+    auto load_pre = [&](long t0, int nvalid) __attribute__((always_inline)) {
+        if (g.vec4) {
+            const int n4 = g.D >> 2;
+            const f32x4 *X4 = reinterpret_cast<const f32x4 *>(a.X + t0 * (long)g.D);
+#pragma unroll
+            for (int i = 0; i < PRE / 4; ++i) {
+                const int e = tid + i * nthr;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (e < n_el && e / n4 < nvalid) v = X4[e];
+                pre[4 * i + 0] = v[0];
+                pre[4 * i + 1] = v[1];
+                pre[4 * i + 2] = v[2];
+                pre[4 * i + 3] = v[3];
+            }
+        } else {
+            const float *Xs = a.X + t0 * (long)g.D;
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) {
+                const int e = tid + i * nthr;
+                pre[i] = (e < n_el && e / g.D < nvalid) ? Xs[e] : 0.f;
+            }
+        }
+    };
+    auto store_pre = [&](float *dst) __attribute__((always_inline)) {
+        if (g.vec4) {
+            const int n4 = g.D >> 2;
+#pragma unroll
+            for (int i = 0; i < PRE / 4; ++i) {
+                const int e = tid + i * nthr;
+                if (e < n_el) {
+                    const int row = e / n4, c4 = e - row * n4;
+                    f32x4 v = {pre[4 * i], pre[4 * i + 1], pre[4 * i + 2], pre[4 * i + 3]};
+                    *reinterpret_cast<f32x4 *>(dst + row * g.XS + 4 * c4) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) {
+                const int e = tid + i * nthr;
+                if (e < n_el) {
+                    const int row = e / g.D;
+                    dst[row * g.XS + (e - row * g.D)] = pre[i];
+                }
+            }
+        }
+    };
+
+    if (ta < tb) {
+        const long t0 = ta << 5;
+        load_pre(t0, (int)((a.T - t0) < 32 ? (a.T - t0) : 32));
+        store_pre(xs);
+    }
+    __syncthreads();
+
+    int cur = 0, since = 0;
+    for (long tile = ta; tile < tb; ++tile) {
+        const long t0 = tile << 5;
+        const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
+        const int nxt = (cur == 2) ? 0 : cur + 1;
+        const int pslot = (int)((tile - ta) & 1);
+        const bool has_next = tile + 1 < tb;
+        if (has_next) {
+            const long t1 = (tile + 1) << 5;
+            load_pre(t1, (int)((a.T - t1) < 32 ? (a.T - t1) : 32));
+        }
+        const float *xt = xs + cur * tile_floats;
+
+        f32x16 lg[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lg[ct][r] = kcv[ct];
+        gemm_logits<NCT>(lg, xt + c * g.XS, h, Wg4, g);
+
+        float mym, mys;
+        wave_lse_reduce<NCT>(lg, c, mym, mys);
+        if ((c & 1) == 0) {
+            const int frame = acc_row((c >> 1) & 15, h);
+            partm[(pslot * NWV + wave) * 32 + frame] = mym;
+            parts[(pslot * NWV + wave) * 32 + frame] = mys;
+        }
+        // next tile goes to the buffer last read two tiles ago (every wave is past that tile's barrier)
+        if (has_next) store_pre(xs + nxt * tile_floats);
+        __syncthreads();
+
+        // combine the NWV partial pairs of every frame (each wave for itself), lse to wave-private LDS
+        {
+            const float *pmv = partm + pslot * NWV * 32 + c;
+            const float *psv = parts + pslot * NWV * 32 + c;
+            float m = pmv[0];
+            for (int w = 1; w < NWV; ++w) m = fmaxf(m, pmv[w * 32]);
+            float sum = 0.f;
+            for (int w = 0; w < NWV; ++w) sum += psv[w * 32] * __builtin_amdgcn_exp2f(pmv[w * 32] - m);
+            const float l2 = m + __builtin_amdgcn_logf(sum);
+            const bool valid = c < nvalid;
+            if (h == 0) ls[c] = valid ? l2 : 3.0e38f;
+            if (wave == 0 && h == 0 && valid) llk_lane += (double)l2;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                lg[ct][4 * q4 + 0] = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + 0] - l4[0]);
+                lg[ct][4 * q4 + 1] = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + 1] - l4[1]);
+                lg[ct][4 * q4 + 2] = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + 2] - l4[2]);
+                lg[ct][4 * q4 + 3] = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + 3] - l4[3]);
+            }
+        }
+        gemm_stats<NJT, NCT, true>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
+        wave_lds_fence();
+        if (++since == SKM_FLUSH_TILES) {
+            flush_slab<NCT, NF>(acc, slab_lane);
+            since = 0;
+        }
+        cur = nxt;
+    }
+    if (since) flush_slab<NCT, NF>(acc, slab_lane);
+    if (wave == 0) {
+#pragma unroll
+        for (int msk = 1; msk < 32; msk <<= 1) llk_lane += __shfl_xor(llk_lane, msk);
+        if (lane == 0) a.llk_part[blockIdx.x] = llk_lane * 0.6931471805599453094;
     }
 }
 
@@ -687,6 +937,9 @@ struct Plan {
     int nct2, nw2, n_cb2, n_fs2, nf2;
     size_t lds2;
     int n_llk;
+    // single-sweep kernel (7..16 component tiles, D <= 63)
+    int fused, fused_nwv, fused_blocks;
+    size_t fused_lds;
     // workspace offsets (bytes)
     size_t off_pm, off_ps, off_lse, off_llk, off_slabs, total;
 };
@@ -743,6 +996,11 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
     p->n_fs1 = wgs / p->n_cb1 > 0 ? wgs / p->n_cb1 : 1;
     p->n_fs2 = wgs / p->n_cb2 > 0 ? wgs / p->n_cb2 : 1;
     p->n_llk = 1024;
+    p->fused = (with_s && g.CT >= 7 && g.CT <= 16 && g.NJT <= 2 && !getenv("SKM_NO_FUSED")) ? 1 : 0;
+    p->fused_nwv = (g.CT + 1) / 2;
+    p->fused_blocks = wgs * (p->fused_nwv <= 4 ? 2 : 1);
+    if (p->fused_blocks > p->n_llk) p->fused_blocks = p->n_llk;
+    p->fused_lds = ((size_t)3 * 32 * g.XS + (size_t)4 * p->fused_nwv * 32 + (size_t)p->fused_nwv * 32) * sizeof(float);
     size_t off = 0;
     p->off_pm = off;
     off += skm_align_up((size_t)p->n_cb1 * (size_t)T * sizeof(float), 256);
@@ -760,7 +1018,10 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         while (nw > 1 && lds_bytes(nct, nw, g) > SKM_LDS_BUDGET) nw >>= 1;
         const int ncb = (g.CT + nct - 1) / nct;
         const int nfs = wgs / ncb > 0 ? wgs / ncb : 1;
-        off += skm_align_up((size_t)ncb * nfs * nw * nct * 32 * nf * 32 * sizeof(double), 256);
+        size_t sl = (size_t)ncb * nfs * nw * nct * 32 * nf * 32 * sizeof(double);
+        const size_t slf = (size_t)p->fused_blocks * p->fused_nwv * 64 * nf * 32 * sizeof(double);
+        if (p->fused && slf > sl) sl = slf;
+        off += skm_align_up(sl, 256);
     }
     p->total = off;
     return SKM_OK;
@@ -888,6 +1149,37 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
     char *ws = static_cast<char *>(ws_);
     const float *wp = static_cast<const float *>(packed);
     const float *kc = wp + (size_t)p.g.CTpad * p.g.NCH * 256;
+    if (p.fused) {
+        // single sweep: all components in one workgroup (C <= 512)
+        FusedArgs f;
+        f.X = X;
+        f.T = T;
+        f.g = p.tg;
+        f.wp = wp;
+        f.kc = kc;
+        f.slabs = reinterpret_cast<double *>(ws + p.off_slabs);
+        f.llk_part = reinterpret_cast<double *>(ws + p.off_llk);
+        const int nwv = p.fused_nwv, nblk = p.fused_blocks, nf = 2 * p.g.NJT;
+        SKM_HIP(hipMemsetAsync(f.slabs, 0, (size_t)nblk * nwv * 64 * nf * 32 * sizeof(double), st));
+        SKM_HIP(hipMemsetAsync(f.llk_part, 0, p.n_llk * sizeof(double), st));
+        {
+            SkmProfScope ps(ctx, "k_estep_fused", st);
+            if (p.g.NJT == 1) {
+                if ((rc = set_lds(k_estep_fused<1>, p.fused_lds))) return rc;
+                hipLaunchKernelGGL(k_estep_fused<1>, dim3(nblk), dim3(64 * nwv), p.fused_lds, st, f);
+            } else {
+                if ((rc = set_lds(k_estep_fused<2>, p.fused_lds))) return rc;
+                hipLaunchKernelGGL(k_estep_fused<2>, dim3(nblk), dim3(64 * nwv), p.fused_lds, st, f);
+            }
+        }
+        SKM_HIP(hipGetLastError());
+        const long n_out = (long)C * nf * 32;
+        SkmProfScope ps(ctx, "k_reduce_slabs", st);
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, f.slabs, nwv, nblk,
+                           1, 2, p.g.NJT, nf, C, D, out, accumulate, f.llk_part, p.n_llk);
+        SKM_HIP(hipGetLastError());
+        return SKM_OK;
+    }
     if ((rc = launch_lse(ctx, p, X, T, wp, kc, ws, nullptr, st))) return rc;
     StatsArgs a;
     memset(&a, 0, sizeof(a));
