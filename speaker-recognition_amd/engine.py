@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libskm.so")
+LIB_PATH = os.environ.get("SKM_LIB") or os.path.join(_HERE, "libskm.so")
 
 _c_void_p = ctypes.c_void_p
 _c_size_t = ctypes.c_size_t
