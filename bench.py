@@ -249,18 +249,18 @@ def main():
         del stat1
         fa = sk.FactorAnalyser()
         T_dev = torch.as_tensor(0.1 * np.random.RandomState(7).randn(Ct * D, R), device=dev)
-        T_dev = fa._tv_iteration(ft, naug, T_dev, Ct, D, R, St, True, 256)       # warm-up iteration
+        T_dev = fa._tv_iteration(ft, naug, T_dev, Ct, D, R, St, True, 1024)      # warm-up iteration
         torch.cuda.synchronize()
         eng.profile(True)
         t0 = time.perf_counter()
-        T_dev = fa._tv_iteration(ft, naug, T_dev, Ct, D, R, St, True, 256)
+        T_dev = fa._tv_iteration(ft, naug, T_dev, Ct, D, R, St, True, 1024)
         torch.cuda.synchronize()
         dt_tv = time.perf_counter() - t0
         prof_tv = eng.profile_read()
         T32, G = eng.tv_prepare(T_dev, Ct, D)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        e_h, _ = eng.tv_estep(naug, ft, T32, G, Ct, D, batch=256, uncertainty=True)
+        e_h, _ = eng.tv_estep(naug, ft, T32, G, Ct, D, batch=1024, uncertainty=True)
         torch.cuda.synchronize()
         dt_iv = time.perf_counter() - t0
         prof_iv = eng.profile_read()

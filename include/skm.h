@@ -106,6 +106,7 @@ int skm_moments(void *ctx, const float *X_dev, long T, int D, double *out_dev,
 #define SKM_GEMM_F32_F64ACC 1  /* float MFMA, accumulators folded into float64 every 512 k, C double   */
 #define SKM_GEMM_F64_F64    2  /* double MFMA (v_mfma_f64_16x16x4_f64), C double                        */
 #define SKM_GEMM_F64_F32OUT 3  /* double MFMA, C float                                                  */
+#define SKM_GEMM_F32_F64OUT 4  /* float MFMA, plain float accumulation (short K), C double               */
 
 /* Strided-batched row-major GEMM  C[z] = alpha op(A[z]) op(B[z]) + beta C[z]  (all pointers dev; trans
  * flags mean "stored transposed").  Replaces the numpy.dot call sites of the TV path that are plain
@@ -117,10 +118,14 @@ int skm_gemm(void *ctx, int kind, const void *A, const void *B, void *C, int M, 
 /* Workspace bytes of skm_tv_estep (S sessions) / skm_tv_mstep (pass S = 0) for a given batch. */
 size_t skm_tv_workspace_bytes(void *ctx, int C, int D, int R, long S, int batch);
 
+/* Row stride (floats) of the augmented zero-order matrix naug = [stat0 | 1 | zero pad]: C + 1 rounded up
+ * to a multiple of 4 so that rows stay 16-byte aligned for the GEMM's vector loads. */
+int skm_tv_naug_stride(int C);
+
 /* Centre and whiten first-order statistics and build the augmented zero-order matrix:
  *   ftilde[S*C*D] float32 = (stat1 - stat0[:,c] * mu) * sqrt(invcov)   with the reference's rounding (in
  *   place in the INPUT dtype: float32 statistics are rounded to float32 after each of the two updates),
- *   naug[S*(C+1)] float32 = [stat0 | 1].
+ *   naug[S*skm_tv_naug_stride(C)] float32 = [stat0 | 1 | 0-pad].
  * in_f64 = 0: stat0/stat1 are float32 (statistics read from a StatServer file), 1: float64.
  * Replaces sidekit/factor_analyser.py:76-79 (and StatServer.whiten_stat1, statserver.py:743-745). */
 int skm_tv_whiten(void *ctx, const void *stat0_dev, const void *stat1_dev, int in_f64, long S, int C, int D,

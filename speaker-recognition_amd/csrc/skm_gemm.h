@@ -11,6 +11,8 @@
 // Extras used by the blocked Cholesky / TV E-step:
 //   tile_mask  0: all of C, 1: only the 32 x 32 blocks of C on or above the block diagonal (column block >=
 //              row block) are written; everything else of C is left untouched
+//   colmap     flattened view of "the part of every row of an R x R matrix at/right of its diagonal block":
+//              one dense GEMM over sum_z (R - col0(z)) logical columns instead of R small ones (tri_n mode)
 //   tri_n > 0  "triangular rows" batch mode: batch z is row z of a [tri_n x tri_n] matrix stored behind
 //              B and C (row stride tri_ldz); only columns >= col0(z) = (z / tri_blk) * tri_blk are produced:
 //              B += z*tri_ldz + col0, C += z*tri_ldz + col0, N = tri_n - col0.  (A is shared.)
@@ -30,6 +32,12 @@ struct GemmArgs {
     int mask_blk;  // block size of tile_mask (32)
     int tri_n, tri_blk;
     long tri_ldz;
+    int vec;  // set by skm_gemm_launch: bit 0 / bit 1 = 16-byte vector loads legal for A / B
+    // optional column map (device, N ints): logical column n of B and C lives at element offset colmap[n]
+    // of a stored row (B not transposed).  colmap_vec: 4 logical columns starting at a multiple of 4 are
+    // contiguous and 16-byte aligned.
+    const int *colmap;
+    int colmap_vec;
 };
 
 static inline GemmArgs skm_gemm_args(const void *A, const void *B, void *C, int M, int N, int K, long lda,
@@ -57,6 +65,7 @@ static inline GemmArgs skm_gemm_args(const void *A, const void *B, void *C, int 
 // kind: input/compute type and output type
 //   SKM_GEMM_F32_F32     A,B float,  C float
 //   SKM_GEMM_F32_F64ACC  A,B float,  C double (f64 folding of the accumulators)
+//   SKM_GEMM_F32_F64OUT  A,B float,  C double (plain f32 accumulation, for short K)
 //   SKM_GEMM_F64_F64     A,B double, C double
 //   SKM_GEMM_F64_F32OUT  A,B double, C float
 int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStream_t st, const char *tag);

@@ -24,18 +24,102 @@ struct Mf<double> {
     static __device__ __forceinline__ int row(int r, int lane) { return (lane >> 4) + 4 * r; }
 };
 
+// Operand tile loader: BROWS x BK logical tile (row = m or n, col = k), 256 threads, 16-byte vectors along
+// the contiguous dimension of the stored matrix when `vec` (alignment checked on the host).
+//   kfast: the stored matrix is contiguous along k (A not transposed / B transposed), else along the row.
+template <typename TI, int BROWS, int BK>
+struct TileIO {
+    static constexpr int VW = 16 / sizeof(TI);
+    static constexpr int NV = BROWS * BK / VW / 256;  // vectors per thread
+    typedef TI vec_t __attribute__((ext_vector_type(16 / sizeof(TI))));
+
+    // (row, k) of element 0 of vector i of thread tid
+    static __device__ __forceinline__ void coord(int tid, int i, bool kfast, int &row, int &k)
+    {
+        const int e = tid + i * 256;
+        if (kfast) {
+            k = (e % (BK / VW)) * VW;
+            row = e / (BK / VW);
+        } else {
+            row = (e % (BROWS / VW)) * VW;
+            k = e / (BROWS / VW);
+        }
+    }
+
+    // map != nullptr (row-fast layouts only): logical row gr lives at element offset map[gr] of a stored row
+    // (flattened "rows right of the diagonal block" view of an R x R matrix; 4 consecutive logical rows that
+    // start at a multiple of 4 are contiguous when vec is set)
+    static __device__ __forceinline__ void load(TI (&r)[NV * VW], const TI *__restrict__ P, long ld, bool kfast, bool vec,
+                                               int row0, int k0, int rows, int K, int tid,
+                                               const int *__restrict__ map = nullptr)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int row, k;
+            coord(tid, i, kfast, row, k);
+            const int gr = row0 + row, gk = k0 + k;
+            if (map && !kfast) {
+                const TI *pk = P + (long)gk * ld;
+                const bool fullm = gk < K && gr + VW <= rows;
+                if (vec && fullm) {
+                    const vec_t v = *reinterpret_cast<const vec_t *>(pk + map[gr]);
+#pragma unroll
+                    for (int j = 0; j < VW; ++j) r[i * VW + j] = v[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VW; ++j) r[i * VW + j] = (gk < K && gr + j < rows) ? pk[map[gr + j]] : (TI)0;
+                }
+                continue;
+            }
+            const TI *p = kfast ? (P + (long)gr * ld + gk) : (P + (long)gk * ld + gr);
+            const bool full = kfast ? (gr < rows && gk + VW <= K) : (gk < K && gr + VW <= rows);
+            if (vec && full) {
+                const vec_t v = *reinterpret_cast<const vec_t *>(p);
+#pragma unroll
+                for (int j = 0; j < VW; ++j) r[i * VW + j] = v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < VW; ++j) {
+                    const bool ok = kfast ? (gr < rows && gk + j < K) : (gk < K && gr + j < rows);
+                    r[i * VW + j] = ok ? p[j] : (TI)0;
+                }
+            }
+        }
+    }
+
+    // LDS image: T[k][row], row stride LDT
+    static __device__ __forceinline__ void store(const TI (&r)[NV * VW], TI *T, int LDT, bool kfast, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int row, k;
+            coord(tid, i, kfast, row, k);
+            if (kfast) {
+#pragma unroll
+                for (int j = 0; j < VW; ++j) T[(k + j) * LDT + row] = r[i * VW + j];
+            } else {
+                vec_t v;
+#pragma unroll
+                for (int j = 0; j < VW; ++j) v[j] = r[i * VW + j];
+                *reinterpret_cast<vec_t *>(T + k * LDT + row) = v;
+            }
+        }
+    }
+};
+
 template <typename TI, typename TO, bool ACC64>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
 {
     typedef Mf<TI> M;
     constexpr int TM = M::TM, KS = M::KS, NR = M::NR;
-    constexpr int BM = 4 * TM, BN = 4 * TM, BK = 16, PAD = 1;
-    constexpr int LDT = BM + PAD;
-    constexpr int EPT = BM * BK / 256;  // elements per thread per operand tile
-    constexpr int FOLD = 32;            // k-tiles between f64 folds (ACC64)
+    constexpr int BM = 4 * TM, BN = 4 * TM;
+    constexpr int BK = (sizeof(TI) == 4 && !ACC64) ? 32 : 16;
+    constexpr int LDT = BM + 16 / sizeof(TI);  // rows stay 16-byte aligned
+    constexpr int FOLD = 512 / BK;             // k-tiles between f64 folds (ACC64): every 512 k
+    typedef TileIO<TI, BM, BK> IO;
 
-    __shared__ TI As[BK * LDT];
-    __shared__ TI Bs[BK * LDT];
+    __shared__ __align__(16) TI As[2][BK * LDT];
+    __shared__ __align__(16) TI Bs[2][BK * LDT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -55,70 +139,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
     if (n0 >= N || m0 >= g.M) return;
     if (g.tile_mask == 1 && (n0 + BN - 1) / g.mask_blk < m0 / g.mask_blk) return;
     const int Mr = g.M, K = g.K;
+    const bool akfast = !g.transA, bkfast = g.transB != 0;
+    const bool avec = (g.vec & 1) != 0, bvec = (g.vec & 2) != 0;
 
-    TI ra[EPT], rb[EPT];
-    auto load_tiles = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int e = tid + i * 256;
-            int m, k;
-            if (g.transA) {
-                m = e % BM;
-                k = e / BM;
-            } else {
-                k = e % BK;
-                m = e / BK;
-            }
-            const int gm = m0 + m, gk = k0 + k;
-            TI v = 0;
-            if (gm < Mr && gk < K) v = g.transA ? A[(long)gk * g.lda + gm] : A[(long)gm * g.lda + gk];
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int e = tid + i * 256;
-            int n, k;
-            if (g.transB) {
-                k = e % BK;
-                n = e / BK;
-            } else {
-                n = e % BN;
-                k = e / BN;
-            }
-            const int gn = n0 + n, gk = k0 + k;
-            TI v = 0;
-            if (gn < N && gk < K) v = g.transB ? B[(long)gn * g.ldb + gk] : B[(long)gk * g.ldb + gn];
-            rb[i] = v;
-        }
-    };
-    auto store_tiles = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int e = tid + i * 256;
-            int m, k;
-            if (g.transA) {
-                m = e % BM;
-                k = e / BM;
-            } else {
-                k = e % BK;
-                m = e / BK;
-            }
-            As[k * LDT + m] = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int e = tid + i * 256;
-            int n, k;
-            if (g.transB) {
-                k = e % BK;
-                n = e / BK;
-            } else {
-                n = e % BN;
-                k = e / BN;
-            }
-            Bs[k * LDT + n] = rb[i];
-        }
-    };
+    TI ra[IO::NV * IO::VW], rb[IO::NV * IO::VW];
 
     typename M::acc_t acc[2][2];
     double acc64[ACC64 ? 2 : 1][ACC64 ? 2 : 1][ACC64 ? NR : 1];
@@ -134,19 +158,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
 
     const int nk = (K + BK - 1) / BK;
     const int lm = lane % TM, lk = lane / TM;
-    load_tiles(0);
-    store_tiles();
+    IO::load(ra, A, g.lda, akfast, avec, m0, 0, Mr, K, tid);
+    IO::load(rb, B, g.ldb, bkfast, bvec, n0, 0, N, K, tid, g.colmap);
+    IO::store(ra, As[0], LDT, akfast, tid);
+    IO::store(rb, Bs[0], LDT, bkfast, tid);
     __syncthreads();
     int since = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            IO::load(ra, A, g.lda, akfast, avec, m0, (kt + 1) * BK, Mr, K, tid);
+            IO::load(rb, B, g.ldb, bkfast, bvec, n0, (kt + 1) * BK, N, K, tid, g.colmap);
+        }
+        const TI *Ac = As[cur] + wm * 2 * TM + lm;
+        const TI *Bc = Bs[cur] + wn * 2 * TM + lm;
 #pragma unroll
         for (int kk = 0; kk < BK / KS; ++kk) {
             TI a[2], b[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = As[(kk * KS + lk) * LDT + wm * 2 * TM + mi * TM + lm];
+            for (int mi = 0; mi < 2; ++mi) a[mi] = Ac[(kk * KS + lk) * LDT + mi * TM];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = Bs[(kk * KS + lk) * LDT + wn * 2 * TM + ni * TM + lm];
+            for (int ni = 0; ni < 2; ++ni) b[ni] = Bc[(kk * KS + lk) * LDT + ni * TM];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -164,9 +196,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
                         acc[mi][ni][r] = 0;
                     }
         }
-        __syncthreads();
         if (kt + 1 < nk) {
-            store_tiles();
+            // the other buffer was last read before the previous barrier: one barrier per k-tile
+            IO::store(ra, As[cur ^ 1], LDT, akfast, tid);
+            IO::store(rb, Bs[cur ^ 1], LDT, bkfast, tid);
             __syncthreads();
         }
     }
@@ -184,11 +217,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
                     double v = (double)acc[mi][ni][r];
                     if (ACC64) v += acc64[mi][ni][r];
                     v *= g.alpha;
-                    TO *p = C + (long)gm * g.ldc + gn;
+                    TO *p = C + (long)gm * g.ldc + (g.colmap ? g.colmap[gn] : gn);
                     if (g.beta != 0.0) v += g.beta * (double)(*p);
                     *p = (TO)v;
                 }
             }
+}
+
+// 16-byte vector loads are legal for an operand when base, leading dimension, batch stride and the
+// triangular-rows offsets all keep 16-byte alignment.
+static int vec_ok(const void *p, long ld, long stride, long tri_ldz, int tri_on, size_t esz)
+{
+    const long vw = (long)(16 / esz);
+    if (((uintptr_t)p & 15) || (ld % vw) || (stride % vw)) return 0;
+    if (tri_on && (tri_ldz % vw)) return 0;
+    return 1;
 }
 
 int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStream_t st, const char *tag)
@@ -196,16 +239,24 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
     SKM_REQUIRE(g.A && g.B && g.C, "gemm(%s): NULL operand", tag);
     SKM_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0 && batch > 0, "gemm(%s): bad shape M=%d N=%d K=%d batch=%d", tag,
                 g.M, g.N, g.K, batch);
-    const int tile = (kind == SKM_GEMM_F32_F32 || kind == SKM_GEMM_F32_F64ACC) ? 128 : 64;
+    const int tile = (kind == SKM_GEMM_F32_F32 || kind == SKM_GEMM_F32_F64ACC || kind == SKM_GEMM_F32_F64OUT) ? 128 : 64;
     const int ncols = g.tri_n > 0 ? g.tri_n : g.N;
     const dim3 grid((ncols + tile - 1) / tile, (g.M + tile - 1) / tile, batch);
     SKM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm(%s): grid too large", tag);
+    SKM_REQUIRE(!g.colmap || (!g.transB && g.tile_mask == 0 && g.tri_n == 0), "gemm(%s): colmap needs plain B", tag);
+    const size_t esz = (kind == SKM_GEMM_F64_F64 || kind == SKM_GEMM_F64_F32OUT) ? 8 : 4;
+    GemmArgs gv = g;
+    gv.vec = (vec_ok(g.A, g.lda, g.sA, 0, 0, esz) ? 1 : 0) |
+             (vec_ok(g.B, g.ldb, g.sB, g.tri_ldz, g.tri_n > 0 && g.tri_blk % (16 / (int)esz) == 0, esz) ? 2 : 0);
+    if (g.tri_n > 0 && g.tri_blk % (16 / (int)esz) != 0) gv.vec &= 1;
+    if (g.colmap && !g.colmap_vec) gv.vec &= 1;
     SkmProfScope ps(ctx, tag, st);
     switch (kind) {
-    case SKM_GEMM_F32_F32: hipLaunchKernelGGL((k_gemm<float, float, false>), grid, dim3(256), 0, st, g); break;
-    case SKM_GEMM_F32_F64ACC: hipLaunchKernelGGL((k_gemm<float, double, true>), grid, dim3(256), 0, st, g); break;
-    case SKM_GEMM_F64_F64: hipLaunchKernelGGL((k_gemm<double, double, false>), grid, dim3(256), 0, st, g); break;
-    case SKM_GEMM_F64_F32OUT: hipLaunchKernelGGL((k_gemm<double, float, false>), grid, dim3(256), 0, st, g); break;
+    case SKM_GEMM_F32_F32: hipLaunchKernelGGL((k_gemm<float, float, false>), grid, dim3(256), 0, st, gv); break;
+    case SKM_GEMM_F32_F64ACC: hipLaunchKernelGGL((k_gemm<float, double, true>), grid, dim3(256), 0, st, gv); break;
+    case SKM_GEMM_F32_F64OUT: hipLaunchKernelGGL((k_gemm<float, double, false>), grid, dim3(256), 0, st, gv); break;
+    case SKM_GEMM_F64_F64: hipLaunchKernelGGL((k_gemm<double, double, false>), grid, dim3(256), 0, st, gv); break;
+    case SKM_GEMM_F64_F32OUT: hipLaunchKernelGGL((k_gemm<double, float, false>), grid, dim3(256), 0, st, gv); break;
     default: skm_set_error("gemm(%s): unknown kind %d", tag, kind); return SKM_ERR_ARG;
     }
     SKM_HIP(hipGetLastError());

@@ -24,6 +24,9 @@
 
 #define TV_BLK 32
 
+// row stride of naug = [N | 1 | 0-pad]: C+1 rounded up to 4 floats so that rows stay 16-byte aligned
+static inline int tv_ldn(int C) { return (C + 1 + 3) / 4 * 4; }
+
 // ------------------------------------------------------------------------------------------------
 // whitening (factor_analyser.py:76-79): in place in the input dtype in the reference; with float32
 // statistics every update is computed in float64 and rounded to float32, which is reproduced here.
@@ -32,7 +35,7 @@ template <typename TS>
 __global__ __launch_bounds__(256) void k_tv_whiten(const TS *__restrict__ stat0, const TS *__restrict__ stat1,
                                                    long S, int C, int D, const double *__restrict__ mu,
                                                    const double *__restrict__ sqrt_ic, float *__restrict__ ft,
-                                                   float *__restrict__ naug)
+                                                   float *__restrict__ naug, int ldn)
 {
     const long CD = (long)C * D;
     const long total = S * CD;
@@ -48,11 +51,39 @@ __global__ __launch_bounds__(256) void k_tv_whiten(const TS *__restrict__ stat0,
             ft[i] = (float)(((double)stat1[i] - n * mu[idx]) * sqrt_ic[idx]);
         }
     }
-    const long totn = S * (C + 1);
+    const long totn = S * ldn;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < totn; i += (long)gridDim.x * blockDim.x) {
-        const long s = i / (C + 1);
-        const int c = (int)(i - s * (C + 1));
-        naug[i] = (c < C) ? (float)stat0[s * C + c] : 1.0f;
+        const long s = i / ldn;
+        const int c = (int)(i - s * ldn);
+        naug[i] = (c < C) ? (float)stat0[s * C + c] : (c == C ? 1.0f : 0.0f);
+    }
+}
+
+// Column map of the flattened upper-block view of an R x R matrix: for row z (block b = z / 32) the logical
+// columns start(z) .. start(z) + R - 32 b - 1 map to element offsets z*R + 32 b + j.
+static inline long tv_tri_cols(int R)
+{
+    long n = 0;
+    for (int z = 0; z < R; ++z) n += R - (z / TV_BLK) * TV_BLK;
+    return n;
+}
+
+__global__ __launch_bounds__(256) void k_tri_map(int *__restrict__ map, int R)
+{
+    const int z = blockIdx.x;
+    const int b = z / TV_BLK, col0 = b * TV_BLK;
+    // start(z) = sum_{b' < b} 32 (R - 32 b') + (z - 32 b)(R - 32 b)
+    long start = (long)TV_BLK * ((long)b * R - (long)TV_BLK * b * (b - 1) / 2) + (long)(z - col0) * (R - col0);
+    for (int j = threadIdx.x; j < R - col0; j += blockDim.x) map[start + j] = z * R + col0 + j;
+}
+
+// Sum nz slabs of n doubles (fixed order).
+__global__ __launch_bounds__(256) void k_sum_slabs(double *__restrict__ dst, const double *__restrict__ src, long n, int nz)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int z = 0; z < nz; ++z) s += src[(long)z * n + i];
+        dst[i] = s;
     }
 }
 
@@ -222,10 +253,20 @@ static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int
 }
 
 struct TvWs {
-    size_t off_mb, off_linv, off_e, off_tb, off_aux, off_eh32, total;
+    size_t off_mb, off_linv, off_e, off_tb, off_aux, off_eh32, off_map, off_auxs, total;
+    int ksplit;
 };
 
-static TvWs tv_ws(int R, long S, int batch)
+// split-K factor of the aux = f~ T GEMM: few sessions give too few 128 x 128 output tiles to fill the chip
+static int tv_ksplit(int cu, long S, int R, int C)
+{
+    const long tiles = ((S + 127) / 128) * ((R + 127) / 128);
+    int ks = 1;
+    while (ks < 16 && tiles * ks < 2L * cu && C % (ks * 2) == 0) ks *= 2;
+    return ks;
+}
+
+static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0)
 {
     TvWs w;
     const size_t RR = (size_t)R * R;
@@ -242,17 +283,23 @@ static TvWs tv_ws(int R, long S, int batch)
     off += skm_align_up((size_t)S * R * sizeof(double), 256);
     w.off_eh32 = off;
     off += skm_align_up((size_t)S * R * sizeof(float), 256);
+    w.off_map = off;
+    off += skm_align_up((size_t)tv_tri_cols(R) * sizeof(int), 256);
+    w.ksplit = (S > 0 && C > 0) ? tv_ksplit(cu, S, R, C) : 1;
+    w.off_auxs = off;
+    if (w.ksplit > 1) off += skm_align_up((size_t)w.ksplit * S * R * sizeof(double), 256);
     w.total = off;
     return w;
 }
 
+extern "C" int skm_tv_naug_stride(int C) { return tv_ldn(C); }
+
 extern "C" size_t skm_tv_workspace_bytes(void *ctx, int C, int D, int R, long S, int batch)
 {
-    (void)ctx;
-    (void)C;
     (void)D;
     if (R <= 0 || S < 0 || batch <= 0) return 0;
-    return tv_ws(R, S, batch).total;
+    const int cu = ctx ? static_cast<SkmCtx *>(ctx)->cu_count : 256;
+    return tv_ws(R, S, batch, cu, C).total;
 }
 
 extern "C" int skm_tv_whiten(void *ctx_, const void *stat0, const void *stat1, int in_f64, long S, int C, int D,
@@ -266,10 +313,10 @@ extern "C" int skm_tv_whiten(void *ctx_, const void *stat0, const void *stat1, i
     SkmProfScope ps(ctx, "k_tv_whiten", st);
     if (in_f64)
         hipLaunchKernelGGL(k_tv_whiten<double>, dim3(blocks), dim3(256), 0, st, static_cast<const double *>(stat0),
-                           static_cast<const double *>(stat1), S, C, D, mu, sqrt_ic, ftilde, naug);
+                           static_cast<const double *>(stat1), S, C, D, mu, sqrt_ic, ftilde, naug, tv_ldn(C));
     else
         hipLaunchKernelGGL(k_tv_whiten<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float *>(stat0),
-                           static_cast<const float *>(stat1), S, C, D, mu, sqrt_ic, ftilde, naug);
+                           static_cast<const float *>(stat1), S, C, D, mu, sqrt_ic, ftilde, naug, tv_ldn(C));
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }
@@ -302,7 +349,7 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
     SKM_REQUIRE(ctx && naug && ftilde && T32 && G && e_h && ws_, "skm_tv_estep: NULL argument");
     SKM_REQUIRE(S > 0 && C > 0 && D > 0 && R > 0 && batch > 0, "skm_tv_estep: bad shape");
     SKM_REQUIRE((A_aug == nullptr) == (Cacc == nullptr), "skm_tv_estep: A_aug and Cacc go together");
-    const TvWs w = tv_ws(R, S, batch);
+    const TvWs w = tv_ws(R, S, batch, ctx->cu_count, C);
     if (ws_bytes < w.total) {
         skm_set_error("skm_tv_estep: workspace too small (%zu < %zu)", ws_bytes, w.total);
         return SKM_ERR_WORKSPACE;
@@ -315,12 +362,30 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
     double *Tb = reinterpret_cast<double *>(ws + w.off_tb);
     double *aux = reinterpret_cast<double *>(ws + w.off_aux);
     float *eh32 = reinterpret_cast<float *>(ws + w.off_eh32);
-    const long RR = (long)R * R, CD = (long)C * D;
+    const long RR = (long)R * R, CD = (long)C * D, ldn = tv_ldn(C);
     const bool train = A_aug != nullptr;
     int rc;
 
-    // aux = f~ T for every session (factor_analyser.py:88)
+    int *cmap = reinterpret_cast<int *>(ws + w.off_map);
+    const int NT = (int)tv_tri_cols(R);
     {
+        SkmProfScope ps(ctx, "k_tri_map", st);
+        hipLaunchKernelGGL(k_tri_map, dim3(R), dim3(256), 0, st, cmap, R);
+    }
+    SKM_HIP(hipGetLastError());
+    // aux = f~ T for every session (factor_analyser.py:88); split over K (component blocks) when S is small
+    if (w.ksplit > 1) {
+        double *slabs = reinterpret_cast<double *>(ws + w.off_auxs);
+        const long kc = CD / w.ksplit;
+        GemmArgs g = skm_gemm_args(ftilde, T32, slabs, (int)S, R, (int)kc, CD, R, R);
+        g.sA = kc;
+        g.sB = kc * R;
+        g.sC = S * R;
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, g, w.ksplit, st, "k_gemm_aux"))) return rc;
+        SkmProfScope ps(ctx, "k_sum_slabs", st);
+        hipLaunchKernelGGL(k_sum_slabs, dim3(ctx->cu_count * 2), dim3(256), 0, st, aux, slabs, S * R, w.ksplit);
+        SKM_HIP(hipGetLastError());
+    } else {
         GemmArgs g = skm_gemm_args(ftilde, T32, aux, (int)S, R, (int)CD, CD, R, R);
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, g, 1, st, "k_gemm_aux"))) return rc;
     }
@@ -328,11 +393,10 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         const int nb = (int)((S - b0) < batch ? (S - b0) : batch);
         SKM_HIP(hipMemsetAsync(Mb, 0, (size_t)nb * RR * sizeof(double), st));
         // L = sum_c N_sc G_c (identity added by the diagonal-block kernel), rows cut at their diagonal block
-        GemmArgs l = skm_gemm_args(naug + b0 * (C + 1), G, Mb, nb, R, C, C + 1, RR, RR);
-        l.tri_n = R;
-        l.tri_blk = TV_BLK;
-        l.tri_ldz = R;
-        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, l, R, st, "k_gemm_lbuild"))) return rc;
+        GemmArgs l = skm_gemm_args(naug + b0 * ldn, G, Mb, nb, NT, C, ldn, RR, RR);
+        l.colmap = cmap;
+        l.colmap_vec = (R % 4 == 0);
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, l, 1, st, "k_gemm_lbuild"))) return rc;
         if ((rc = blocked_inverse(ctx, Mb, Linv, Tb, nb, R, 1, 1, st))) return rc;
         {
             SkmProfScope ps(ctx, "k_tv_finish", st);
@@ -343,13 +407,12 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         SKM_HIP(hipGetLastError());
         if (train) {
             // A[c] += sum_s N_sc e_hh(s); row C (the ones column of naug) accumulates _R
-            GemmArgs a = skm_gemm_args(naug + b0 * (C + 1), E, A_aug, C + 1, R, nb, C + 1, RR, RR);
+            GemmArgs a = skm_gemm_args(naug + b0 * ldn, E, A_aug, C + 1, NT, nb, ldn, RR, RR);
             a.transA = 1;
             a.beta = 1.0;
-            a.tri_n = R;
-            a.tri_blk = TV_BLK;
-            a.tri_ldz = R;
-            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, a, R, st, "k_gemm_aacc"))) return rc;
+            a.colmap = cmap;
+            a.colmap_vec = (R % 4 == 0);
+            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, a, 1, st, "k_gemm_aacc"))) return rc;
         }
     }
     if (train) {

@@ -40,6 +40,7 @@ SIGNATURES = {
     "skm_gemm": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_long,
                           _c_long, _c_long, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int, _c_long,
                           _c_long, _c_long, _c_void_p]),
+    "skm_tv_naug_stride": (_c_int, [_c_int]),
     "skm_tv_workspace_bytes": (_c_size_t, [_c_void_p, _c_int, _c_int, _c_int, _c_long, _c_int]),
     "skm_tv_whiten": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_int, _c_int, _c_void_p,
                                _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
@@ -257,7 +258,7 @@ class HipEngine(object):
         mu = torch.as_tensor(_as_f64(mu_sv)).to(self.device)
         sq = torch.as_tensor(np.sqrt(_as_f64(invcov_sv))).to(self.device)
         ft = torch.empty((S, CD), dtype=torch.float32, device=self.device)
-        naug = torch.empty((S, C + 1), dtype=torch.float32, device=self.device)
+        naug = torch.empty((S, self.lib.skm_tv_naug_stride(C)), dtype=torch.float32, device=self.device)
         self._check(self.lib.skm_tv_whiten(self.ctx, _c_void_p(stat0.data_ptr()), _c_void_p(stat1.data_ptr()),
                                            1 if stat0.dtype == torch.float64 else 0, S, C, D,
                                            _c_void_p(mu.data_ptr()), _c_void_p(sq.data_ptr()),
@@ -275,7 +276,7 @@ class HipEngine(object):
                                             _c_void_p(G.data_ptr()), self._stream()))
         return T32, G
 
-    def tv_estep(self, naug, ft, T32, G, C, D, batch=256, A_aug=None, Cacc=None, uncertainty=False):
+    def tv_estep(self, naug, ft, T32, G, C, D, batch=1024, A_aug=None, Cacc=None, uncertainty=False):
         """E-step over the sessions of (naug, ft).  Returns (e_h, iv_sigma or None); when A_aug/Cacc are
         given (training) the accumulators are updated in place."""
         torch = self.torch

@@ -176,7 +176,7 @@ class FactorAnalyser(object):
             self.write((output_file_name or "temporary_factor_analyser") + "_init" + self._ext())
 
         ft, naug, total, _ = self._resident_stats(sources, ubm)
-        batch = int(max(1, min(batch_size, 256)))
+        batch = 1024   # device batch: results do not depend on it (the reference batches only to bound host memory)
         T_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(self.F, dtype=np.float64))).to(eng.device)
         for it in range(nb_iter):
             T_dev = self._tv_iteration(ft, naug, T_dev, C, D, tv_rank, total, min_div, batch)
@@ -229,7 +229,7 @@ class FactorAnalyser(object):
         iv_sigma = np.zeros((nb_sessions, tv_rank), dtype=STAT_TYPE)
         a, b = local[0]
         if ft is not None:
-            e_h, sig = self._extract(ft, naug, ubm, int(max(1, min(batch_size, 256))), True)
+            e_h, sig = self._extract(ft, naug, ubm, 1024, True)
             iv[a:b] = eng.to_host(e_h)
             iv_sigma[a:b] = eng.to_host(sig)
         if dist.is_dist():
@@ -261,7 +261,7 @@ class FactorAnalyser(object):
         d1 = torch.from_numpy(np.ascontiguousarray(stat_server.stat1, dtype=np.float64)).to(eng.device)
         ft, naug = eng.tv_whiten(d0, d1, ubm.get_mean_super_vector(), ubm.get_invcov_super_vector())
         stat_server.whiten_stat1(ubm.get_mean_super_vector(), 1. / ubm.get_invcov_super_vector())
-        e_h, sig = self._extract(ft, naug, ubm, 256, True)
+        e_h, sig = self._extract(ft, naug, ubm, 1024, True)
         iv_stat_server = StatServer()
         iv_stat_server.modelset = copy.deepcopy(stat_server.modelset)
         iv_stat_server.segset = copy.deepcopy(stat_server.segset)

@@ -70,7 +70,7 @@ class OracleEngine(object):
     def tv_estep(self, naug, ft, T32, G, C, D, batch=256, A_aug=None, Cacc=None, uncertainty=False):
         Fm = T32.numpy()
         R = Fm.shape[1]
-        n = naug.numpy().astype(np.float64)
+        n = naug.numpy().astype(np.float64)[:, :C + 1]
         f = ft.numpy().astype(np.float64)
         idx = np.repeat(np.arange(C), D)
         e_h = np.zeros((n.shape[0], R))
