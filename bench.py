@@ -193,6 +193,17 @@ def main():
                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                               "traffic": None, "avg_launch_ms": t_dom,
                               "algorithmic_flop_per_launch": flop_dom}
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same workload (a process
+        # cannot read its own PMC counters); the committed summary is used only when the workload matches
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_hbm_traffic.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc["workload"] == {"C": C, "D": D, "frames": T}:
+                for name, rec in pmc["kernels"].items():
+                    if name.startswith(dom):
+                        result["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                        result["roofline"]["traffic_source"] = "profiles/r1_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE)"
+                        result["roofline"]["algorithmic_bytes_per_launch"] = 4.0 * D * T
         achp = flop_path / (t_path * 1e-3) / 1e12
         result["roofline_path"] = {"bound": "mfma", "kernels": {k: round(v, 4) for k, v in kt.items()},
                                    "achieved": achp, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
