@@ -287,6 +287,52 @@ __device__ __forceinline__ void wave_lse_reduce(const f32x16 (&lg)[NCT], int c, 
     s_out = s[0] * __builtin_amdgcn_exp2f(m[0] - nm) + rs * __builtin_amdgcn_exp2f(rm - nm);
 }
 
+// Transposed butterfly without LDS traffic: reduces v[r] (r = frame register) over the 32 component lanes
+// of each wave half with `op`, halving the live registers at every level.  Level 16 is one
+// v_permlane16_swap per register pair, the levels inside a 16-lane row are DPP operands.  On return
+// v[0] of lane (c, h) holds the result for frame acc_row((c >> 1) & 15, h); lanes c and c^1 agree.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+struct OpMax {
+    __device__ __forceinline__ float operator()(float a, float b) const { return __builtin_fmaxf(a, b); }
+};
+struct OpAdd {
+    __device__ __forceinline__ float operator()(float a, float b) const { return a + b; }
+};
+
+template <typename Op>
+__device__ __forceinline__ void lane_reduce16(float (&v)[16], int c, Op op)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        // (hipcc 7.2 returns the first result twice from __builtin_amdgcn_permlane16_swap, hence the asm;
+        // the s_nop pairs cover the VALU-write -> permlane and permlane -> VALU-read wait states, which the
+        // hazard recogniser does not see inside an asm block)
+        float lo = v[j], hi = v[j + 8];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+        v[j] = op(lo, hi);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // lane ^ 8: row_ror:8
+        const float lo = op(v[j], dpp_f32<0x128>(v[j])), hi = op(v[j + 4], dpp_f32<0x128>(v[j + 4]));
+        v[j] = (c & 8) ? hi : lo;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {   // lane -> 7 - lane inside groups of 8: row_half_mirror
+        const float lo = op(v[j], dpp_f32<0x141>(v[j])), hi = op(v[j + 2], dpp_f32<0x141>(v[j + 2]));
+        v[j] = (c & 4) ? hi : lo;
+    }
+    {                               // lane ^ 2: quad_perm [2,3,0,1]
+        const float lo = op(v[0], dpp_f32<0x4E>(v[0])), hi = op(v[1], dpp_f32<0x4E>(v[1]));
+        v[0] = (c & 2) ? hi : lo;
+    }
+    v[0] = op(v[0], dpp_f32<0xB1>(v[0]));   // lane ^ 1: quad_perm [1,0,3,2]
+}
+
 // ------------------------------------------------------------------------------------------------
 // sweep 1: per (component block, frame) partial max / sum of exp2
 // ------------------------------------------------------------------------------------------------
@@ -616,7 +662,23 @@ struct FusedArgs {
     const float *kc;
     double *slabs;     // [n_blocks][NWV] slabs of [64][NF*32] f64 (zeroed by the host)
     double *llk_part;  // [n_blocks]
+    int stagger;       // 0 lock-step, 1 second half of the waves runs half a tile late, 2 and at priority 1
+#ifdef SKM_TRACE
+    long long *trace;  // [NWV][16] cycle stamps of one tile of block 1 (tools/trace_estep.py)
+#endif
 };
+#ifdef SKM_TRACE
+static long long *g_trace = nullptr;
+extern "C" void skm_trace_buffer(void *p) { g_trace = static_cast<long long *>(p); }
+#define SKM_TRACE_DECL bool trace_now = false
+#define SKM_TRACE_TILE trace_now = a.trace && blockIdx.x == 1 && lane == 0 && tile - ta == 40
+#define SKM_STAMP(k) \
+    if (trace_now) a.trace[wave * 16 + (k)] = __builtin_readcyclecounter()
+#else
+#define SKM_TRACE_DECL
+#define SKM_TRACE_TILE
+#define SKM_STAMP(k)
+#endif
 
 template <int NJT>
 __global__ __launch_bounds__(512, 2) void k_estep_fused(FusedArgs a)
@@ -633,6 +695,7 @@ __global__ __launch_bounds__(512, 2) void k_estep_fused(FusedArgs a)
     float *partm = xs + 3 * tile_floats;             // [2][NWV][32]
     float *parts = partm + 2 * NWV * 32;             // [2][NWV][32]
     float *ls = parts + 2 * NWV * 32 + wave * 32;    // wave-private lse[32]
+    f32x4 *stash = reinterpret_cast<f32x4 *>(parts + 2 * NWV * 32 + NWV * 32) + wave * (NCT * 4 * 64) + lane;  // wave-private
 
     // constant padding columns (ones column at D) of the three buffers
     {
@@ -717,69 +780,179 @@ __global__ __launch_bounds__(512, 2) void k_estep_fused(FusedArgs a)
     }
     __syncthreads();
 
-    int cur = 0, since = 0;
-    for (long tile = ta; tile < tb; ++tile) {
-        const long t0 = tile << 5;
-        const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
-        const int nxt = (cur == 2) ? 0 : cur + 1;
-        const int pslot = (int)((tile - ta) & 1);
-        const bool has_next = tile + 1 < tb;
-        if (has_next) {
-            const long t1 = (tile + 1) << 5;
-            load_pre(t1, (int)((a.T - t1) < 32 ? (a.T - t1) : 32));
-        }
-        const float *xt = xs + cur * tile_floats;
-
-        f32x16 lg[NCT];
+    SKM_TRACE_DECL;
+    // logits of one tile and this wave's (max, sum) partials of its 64 components -> LDS slot
+    auto logits_phase = [&](f32x16 (&lg)[NCT], const float *xt, int pslot) __attribute__((always_inline)) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) lg[ct][r] = kcv[ct];
         gemm_logits<NCT>(lg, xt + c * g.XS, h, Wg4, g);
-
-        float mym, mys;
-        wave_lse_reduce<NCT>(lg, c, mym, mys);
-        if ((c & 1) == 0) {
-            const int frame = acc_row((c >> 1) & 15, h);
-            partm[(pslot * NWV + wave) * 32 + frame] = mym;
-            parts[(pslot * NWV + wave) * 32 + frame] = mys;
+        SKM_STAMP(1);
+        // exact per-frame maximum over this wave's components ...
+        float m[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            m[r] = lg[0][r];
+#pragma unroll
+            for (int ct = 1; ct < NCT; ++ct) m[r] = __builtin_fmaxf(m[r], lg[ct][r]);
         }
-        // next tile goes to the buffer last read two tiles ago (every wave is past that tile's barrier)
-        if (has_next) store_pre(xs + nxt * tile_floats);
-        __syncthreads();
-
-        // combine the NWV partial pairs of every frame (each wave for itself), lse to wave-private LDS
+        lane_reduce16(m, c, OpMax());
+        const int frame = acc_row((c >> 1) & 15, h);
+        if ((c & 1) == 0) ls[frame] = m[0];
+        wave_lds_fence();
+        // ... e = 2^(l - max) replaces the logits (each exponential is taken once; gamma = e * factor later),
+        // and the wave's per-frame sum of e
+        float sm[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float acc1 = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const float e = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + i] - m4[i]);
+                    lg[ct][4 * q4 + i] = e;
+                    acc1 += e;
+                }
+                sm[4 * q4 + i] = acc1;
+            }
+        }
+        lane_reduce16(sm, c, OpAdd());
+        if ((c & 1) == 0) {
+            partm[(pslot * NWV + wave) * 32 + frame] = m[0];
+            parts[(pslot * NWV + wave) * 32 + frame] = sm[0];
+        }
+        wave_lds_fence();   // ls is rewritten by stats_phase
+    };
+    // combine the NWV partial pairs of every frame (each wave for itself): gamma = e * 2^(m_wave - m) / sum
+    auto stats_phase = [&](f32x16 (&lg)[NCT], const float *xt, int pslot, int nvalid) __attribute__((always_inline)) {
         {
             const float *pmv = partm + pslot * NWV * 32 + c;
             const float *psv = parts + pslot * NWV * 32 + c;
             float m = pmv[0];
-            for (int w = 1; w < NWV; ++w) m = fmaxf(m, pmv[w * 32]);
+            for (int w = 1; w < NWV; ++w) m = __builtin_fmaxf(m, pmv[w * 32]);
             float sum = 0.f;
             for (int w = 0; w < NWV; ++w) sum += psv[w * 32] * __builtin_amdgcn_exp2f(pmv[w * 32] - m);
-            const float l2 = m + __builtin_amdgcn_logf(sum);
             const bool valid = c < nvalid;
-            if (h == 0) ls[c] = valid ? l2 : 3.0e38f;
-            if (wave == 0 && h == 0 && valid) llk_lane += (double)l2;
+            const float f = __builtin_amdgcn_exp2f(pmv[wave * 32] - m) * __builtin_amdgcn_rcpf(sum);
+            if (h == 0) ls[c] = valid ? f : 0.f;
+            if (wave == 0 && h == 0 && valid) llk_lane += (double)(m + __builtin_amdgcn_logf(sum));
         }
         wave_lds_fence();
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 l4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+            const f32x4 f4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                lg[ct][4 * q4 + 0] = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + 0] - l4[0]);
-                lg[ct][4 * q4 + 1] = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + 1] - l4[1]);
-                lg[ct][4 * q4 + 2] = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + 2] - l4[2]);
-                lg[ct][4 * q4 + 3] = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + 3] - l4[3]);
+                lg[ct][4 * q4 + 0] *= f4[0];
+                lg[ct][4 * q4 + 1] *= f4[1];
+                lg[ct][4 * q4 + 2] *= f4[2];
+                lg[ct][4 * q4 + 3] *= f4[3];
             }
         }
+        SKM_STAMP(5);
         gemm_stats<NJT, NCT, true>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
+        SKM_STAMP(6);
         wave_lds_fence();
-        if (++since == SKM_FLUSH_TILES) {
-            flush_slab<NCT, NF>(acc, slab_lane);
-            since = 0;
+    };
+
+    // Between two workgroup barriers every wave owes: statistics of tile i-1 and logits of tile i.  The two
+    // waves of a SIMD (w, w + NWV/2) run them in opposite order, so one is in its VALU stretch (logsumexp,
+    // exp2) while the other streams MFMAs, instead of both reaching each phase together.
+    const bool late = (a.stagger != 0) && wave >= (NWV >> 1);
+    if (late && a.stagger > 1) __builtin_amdgcn_s_setprio(1);
+    int cur = 0, since = 0;
+    if (!late) {
+        for (long tile = ta; tile < tb; ++tile) {
+            const long t0 = tile << 5;
+            const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
+            const int nxt = (cur == 2) ? 0 : cur + 1;
+            const int pslot = (int)((tile - ta) & 1);
+            const bool has_next = tile + 1 < tb;
+            if (has_next) {
+                const long t1 = (tile + 1) << 5;
+                load_pre(t1, (int)((a.T - t1) < 32 ? (a.T - t1) : 32));
+            }
+            const float *xt = xs + cur * tile_floats;
+            f32x16 lg[NCT];
+            SKM_TRACE_TILE;
+            SKM_STAMP(0);
+            logits_phase(lg, xt, pslot);
+            SKM_STAMP(2);
+            // next tile goes to the buffer last read two tiles ago (every wave is past that tile's barrier)
+            if (has_next) store_pre(xs + nxt * tile_floats);
+            SKM_STAMP(3);
+            __syncthreads();
+            SKM_STAMP(4);
+            stats_phase(lg, xt, pslot, nvalid);
+            SKM_STAMP(7);
+            if (++since == SKM_FLUSH_TILES) {
+                flush_slab<NCT, NF>(acc, slab_lane);
+                since = 0;
+            }
+            cur = nxt;
         }
-        cur = nxt;
+    } else {
+        // the logits of a tile wait in a wave-private LDS stash while the next tile's logits are computed
+        auto swap_stash = [&](f32x16 (&lg)[NCT], bool rd, bool wr) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                    if (rd) o = stash[(ct * 4 + q) * 64];
+                    if (wr) {
+                        const f32x4 n = {lg[ct][4 * q], lg[ct][4 * q + 1], lg[ct][4 * q + 2], lg[ct][4 * q + 3]};
+                        stash[(ct * 4 + q) * 64] = n;
+                    }
+                    lg[ct][4 * q] = o[0];
+                    lg[ct][4 * q + 1] = o[1];
+                    lg[ct][4 * q + 2] = o[2];
+                    lg[ct][4 * q + 3] = o[3];
+                }
+        };
+        int prv = 0;
+        for (long tile = ta; tile < tb; ++tile) {
+            const int nxt = (cur == 2) ? 0 : cur + 1;
+            const int pslot = (int)((tile - ta) & 1);
+            const bool has_next = tile + 1 < tb;
+            if (has_next) {
+                const long t1 = (tile + 1) << 5;
+                load_pre(t1, (int)((a.T - t1) < 32 ? (a.T - t1) : 32));
+            }
+            f32x16 lg[NCT];
+            SKM_TRACE_TILE;
+            SKM_STAMP(0);
+            logits_phase(lg, xs + cur * tile_floats, pslot);
+            SKM_STAMP(2);
+            if (has_next) store_pre(xs + nxt * tile_floats);
+            SKM_STAMP(3);
+            if (tile > ta) {
+                swap_stash(lg, true, true);
+                SKM_STAMP(4);
+                stats_phase(lg, xs + prv * tile_floats, pslot ^ 1, 32);   // only the last tile can be ragged
+                SKM_STAMP(7);
+                if (++since == SKM_FLUSH_TILES) {
+                    flush_slab<NCT, NF>(acc, slab_lane);
+                    since = 0;
+                }
+            } else {
+                swap_stash(lg, false, true);
+            }
+            __syncthreads();
+            SKM_STAMP(8);
+            prv = cur;
+            cur = nxt;
+        }
+        if (ta < tb) {
+            const long t0 = (tb - 1) << 5;
+            f32x16 lg[NCT];
+            swap_stash(lg, true, false);
+            stats_phase(lg, xs + prv * tile_floats, (int)((tb - 1 - ta) & 1), (int)((a.T - t0) < 32 ? (a.T - t0) : 32));
+            ++since;
+        }
     }
     if (since) flush_slab<NCT, NF>(acc, slab_lane);
     if (wave == 0) {
@@ -1000,7 +1173,8 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
     p->fused_nwv = (g.CT + 1) / 2;
     p->fused_blocks = wgs * (p->fused_nwv <= 4 ? 2 : 1);
     if (p->fused_blocks > p->n_llk) p->fused_blocks = p->n_llk;
-    p->fused_lds = ((size_t)3 * 32 * g.XS + (size_t)4 * p->fused_nwv * 32 + (size_t)p->fused_nwv * 32) * sizeof(float);
+    p->fused_lds = ((size_t)3 * 32 * g.XS + (size_t)4 * p->fused_nwv * 32 + (size_t)p->fused_nwv * 32 +
+                    (size_t)p->fused_nwv * 2 * 16 * 64) * sizeof(float);
     size_t off = 0;
     p->off_pm = off;
     off += skm_align_up((size_t)p->n_cb1 * (size_t)T * sizeof(float), 256);
@@ -1159,6 +1333,13 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
         f.kc = kc;
         f.slabs = reinterpret_cast<double *>(ws + p.off_slabs);
         f.llk_part = reinterpret_cast<double *>(ws + p.off_llk);
+#ifdef SKM_TRACE
+        f.trace = g_trace;
+#endif
+        {
+            const char *e = getenv("SKM_STAGGER");
+            f.stagger = e ? atoi(e) : 1;
+        }
         const int nwv = p.fused_nwv, nblk = p.fused_blocks, nf = 2 * p.g.NJT;
         SKM_HIP(hipMemsetAsync(f.slabs, 0, (size_t)nblk * nwv * 64 * nf * 32 * sizeof(double), st));
         SKM_HIP(hipMemsetAsync(f.llk_part, 0, p.n_llk * sizeof(double), st));
