@@ -82,6 +82,15 @@ int skm_gmm_estep(void *ctx, const float *X_dev, long T, int C, int D, const voi
 int skm_gmm_loglik(void *ctx, const float *X_dev, long T, int C, int D, const void *packed_dev,
                    float *loglik_dev, void *ws_dev, size_t ws_bytes, void *stream);
 
+/* lp_dev[T*C] (float64, row-major, dev) = ln(w_c N(x_t; mu_c, Sigma_c)), the matrix returned by
+ * Mixture.compute_log_posterior_probabilities (sidekit/mixture.py:461-487; its `mu=` override is a
+ * second skm_gmm_pack with the replacement means).  loglik_dev (T float32) is optional (NULL) and
+ * receives the row log-sum-exp, i.e. the log_lk of sum_log_probabilities (sidekit/mixture.py:52-64).
+ * Arithmetic is float32 (MFMA), widened on store.  Only callers that need the T x C matrix itself use
+ * this; the statistics entry points never materialise it. */
+int skm_gmm_logprob(void *ctx, const float *X_dev, long T, int C, int D, const void *packed_dev,
+                    double *lp_dev, float *loglik_dev, void *ws_dev, size_t ws_bytes, void *stream);
+
 /* Baum-Welch statistics per session.  Session s owns frames [seg_off[s], seg_off[s+1]) of X
  * (seg_off: S+1 int64 on the device, non-decreasing, seg_off[S] <= T).
  *   stat0_dev[S*C]      float64   zero order  (sum_t gamma)

@@ -345,6 +345,8 @@ struct LseArgs {
     float *pm;        // [n_cb][T]
     float *ps;        // [n_cb][T]
     int n_cb, n_fs;
+    double *lp;       // optional [T][C] natural-log weighted component densities (NULL: not written)
+    int C;
 };
 
 template <int NCT>
@@ -393,6 +395,19 @@ __global__ __launch_bounds__(512, 2) void k_lse_partial(LseArgs a)
 
         gemm_logits<NCT>(lg, xs + c * g.XS, h, Wl4, g);
 
+        if (a.lp) {
+            // lp[t][c] = ln(w_c N(x_t; c)): a row of 32 consecutive components per register
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int comp = (cb * NCT + ct) * 32 + c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int frame = acc_row(r, h);
+                    if (frame < nvalid && comp < a.C)
+                        a.lp[(t0 + frame) * (long)a.C + comp] = (double)lg[ct][r] * 0.6931471805599453094;
+                }
+            }
+        }
         // Row (= frame) logsumexp over the 32 component lanes of each half and the NCT tiles.
         float mym, mys;
         wave_lse_reduce<NCT>(lg, c, mym, mys);
@@ -1218,9 +1233,11 @@ static int set_lds(K kernel, size_t bytes)
 }
 
 static int launch_lse(SkmCtx *ctx, const Plan &p, const float *X, long T, const float *wp, const float *kc,
-                      char *ws, float *loglik, hipStream_t st)
+                      char *ws, float *loglik, hipStream_t st, double *lp = nullptr, int C = 0)
 {
     LseArgs a;
+    a.lp = lp;
+    a.C = C;
     a.X = X;
     a.T = T;
     a.g = p.tg;
@@ -1401,6 +1418,21 @@ extern "C" int skm_gmm_loglik(void *ctx_, const float *X, long T, int C, int D, 
     const float *wp = static_cast<const float *>(packed);
     const float *kc = wp + (size_t)p.g.CTpad * p.g.NCH * 256;
     return launch_lse(ctx, p, X, T, wp, kc, static_cast<char *>(ws_), loglik, (hipStream_t)stream);
+}
+
+extern "C" int skm_gmm_logprob(void *ctx_, const float *X, long T, int C, int D, const void *packed, double *lp,
+                               float *loglik, void *ws_, size_t ws_bytes, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx != nullptr, "skm_gmm_logprob: NULL ctx");
+    Plan p;
+    int rc = make_plan(ctx, T, C, D, true, &p);
+    if (rc) return rc;
+    if ((rc = check_common(ctx_, X, T, C, D, packed, ws_, ws_bytes, p, "skm_gmm_logprob"))) return rc;
+    SKM_REQUIRE(lp != nullptr, "skm_gmm_logprob: lp is NULL");
+    const float *wp = static_cast<const float *>(packed);
+    const float *kc = wp + (size_t)p.g.CTpad * p.g.NCH * 256;
+    return launch_lse(ctx, p, X, T, wp, kc, static_cast<char *>(ws_), loglik, (hipStream_t)stream, lp, C);
 }
 
 extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *seg_off, int S, int C, int D,

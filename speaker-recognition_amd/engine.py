@@ -35,6 +35,8 @@ SIGNATURES = {
                                _c_void_p, _c_size_t, _c_void_p]),
     "skm_gmm_loglik": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p,
                                 _c_void_p, _c_size_t, _c_void_p]),
+    "skm_gmm_logprob": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
+                                 _c_void_p, _c_size_t, _c_void_p]),
     "skm_bw_stats": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
                               _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "skm_gemm": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_long,
@@ -189,6 +191,23 @@ class HipEngine(object):
                                             _c_void_p(gmm.packed.data_ptr()), _c_void_p(out.data_ptr()),
                                             _c_void_p(ws), need, self._stream()))
         return out
+
+    def logprob(self, X, gmm, with_loglik=False):
+        """T x C float64 device matrix ln(w_c N(x_t; c)) [and the T float32 row log-sum-exp]."""
+        torch = self.torch
+        T, D = X.shape
+        assert D == gmm.D and X.dtype == torch.float32 and X.is_contiguous()
+        lp = torch.empty((T, gmm.C), dtype=torch.float64, device=self.device)
+        llk = torch.empty(T, dtype=torch.float32, device=self.device) if with_loglik else None
+        if T == 0:
+            return (lp, llk) if with_loglik else lp
+        need = self.lib.skm_gmm_workspace_bytes(self.ctx, T, gmm.C, D)
+        ws = self.workspace(need)
+        self._check(self.lib.skm_gmm_logprob(self.ctx, _c_void_p(X.data_ptr()), T, gmm.C, D,
+                                             _c_void_p(gmm.packed.data_ptr()), _c_void_p(lp.data_ptr()),
+                                             _c_void_p(llk.data_ptr()) if with_loglik else None,
+                                             _c_void_p(ws), need, self._stream()))
+        return (lp, llk) if with_loglik else lp
 
     def bw_stats(self, X, seg_off, gmm, stat0=None, stat1=None):
         """Per-session N (S x C) and F (S x C*D, component-major), float64 device tensors."""

@@ -157,7 +157,7 @@ class FactorAnalyser(object):
         return F_new
 
     def _train(self, sources, ubm, tv_rank, nb_iter, min_div, tv_init, batch_size, save_init, output_file_name,
-               always_write):
+               always_write, resident=None):
         assert (isinstance(ubm, Mixture) and ubm.validate()), "Second argument must be a proper Mixture"
         assert (isinstance(nb_iter, int) and (0 < nb_iter)), "nb_iter must be a positive integer"
         eng = self.engine
@@ -175,7 +175,10 @@ class FactorAnalyser(object):
         if save_init:
             self.write((output_file_name or "temporary_factor_analyser") + "_init" + self._ext())
 
-        ft, naug, total, _ = self._resident_stats(sources, ubm)
+        if resident is not None:
+            ft, naug, total = resident
+        else:
+            ft, naug, total, _ = self._resident_stats(sources, ubm)
         batch = 1024   # device batch: results do not depend on it (the reference batches only to bound host memory)
         T_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(self.F, dtype=np.float64))).to(eng.device)
         for it in range(nb_iter):
@@ -204,6 +207,29 @@ class FactorAnalyser(object):
         output_file_name is given (:529-533)."""
         self._train([stat_server_filename], ubm, tv_rank, nb_iter, min_div, tv_init, batch_size, save_init,
                     output_file_name, always_write=False)
+
+    def total_variability_raw(self, stat_server, ubm, tv_rank, nb_iter=20, min_div=True, tv_init=None,
+                              save_init=False, output_file_name=None):
+        """In-memory variant (factor_analyser.py:326-428): the StatServer is whitened in float64 (and,
+        like the reference, left whitened), the same EM follows; files are always written
+        ("temporary_factor_analyser" when no name is given, :381-382)."""
+        assert (isinstance(stat_server, StatServer) and stat_server.validate()), \
+            "First argument must be a proper StatServer"
+        assert (isinstance(ubm, Mixture) and ubm.validate()), "Second argument must be a proper Mixture"
+        assert (isinstance(tv_rank, int) and (0 < tv_rank <= min(stat_server.stat1.shape))), \
+            "tv_rank must be a positive integer less than the dimension of the statistics"
+        eng = self.engine
+        torch = eng.torch
+        n = stat_server.stat1.shape[0]
+        a, b = dist.shard_bounds(n) if dist.is_dist() else (0, n)
+        ft = naug = None
+        if b > a:
+            d0 = torch.from_numpy(np.ascontiguousarray(stat_server.stat0[a:b], dtype=np.float64)).to(eng.device)
+            d1 = torch.from_numpy(np.ascontiguousarray(stat_server.stat1[a:b], dtype=np.float64)).to(eng.device)
+            ft, naug = eng.tv_whiten(d0, d1, ubm.get_mean_super_vector(), ubm.get_invcov_super_vector())
+        stat_server.whiten_stat1(ubm.get_mean_super_vector(), 1. / ubm.get_invcov_super_vector())
+        self._train(None, ubm, tv_rank, nb_iter, min_div, tv_init, None, save_init, output_file_name,
+                    always_write=True, resident=(ft, naug, n))
 
     # ------------------------------------------------------------------ extraction
     def _extract(self, ft, naug, ubm, batch, uncertainty):

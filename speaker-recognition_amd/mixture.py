@@ -376,6 +376,22 @@ class Mixture(object):
         self.cov_var_ctl = 1.0 / copy.deepcopy(self.invcov)
         self._compute_all()
 
+    # ------------------------------------------------------------------ T x C matrix (mixture.py:461-487)
+    def compute_log_posterior_probabilities(self, cep, mu=None):
+        """ln(w_c N(x_t; mu_c, Sigma_c)) for every frame and component, T x C float64, computed on the
+        GPU (float32 MFMA, widened on store).  `mu` replaces the means (a C x D array or a C*D
+        super-vector, the MAP-adapted model of gmm_scoring), exactly as mixture.py:474-479 does by
+        recomputing the data-independent term A from it."""
+        cep = np.asarray(cep) if not _is_torch(cep) else cep
+        if cep.ndim == 1:
+            cep = cep[None, :]
+        if mu is None:
+            packed = self._pack()
+        else:
+            packed = self.engine.pack(self.w, np.asarray(mu, dtype=np.float64).reshape(self.mu.shape), self.invcov)
+        X = self._device_frames(cep)
+        return self.engine.to_host(self.engine.logprob(X, packed))
+
     # ------------------------------------------------------------------ scoring helper
     def log_likelihood(self, cep):
         """Per-frame log sum_c w_c N(x_t) on the GPU: the `log_lk` of sum_log_probabilities

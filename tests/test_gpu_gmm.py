@@ -206,3 +206,47 @@ def test_one_em_step_from_identical_params_large(sk, eng):
     orc.maximization(a, N, F, S)
     orc.maximization(b, rN, rF, rS)
     assert rel(a.w, b.w) < TOL and rel(a.mu, b.mu) < TOL and rel(1 / a.invcov, 1 / b.invcov) < TOL
+
+
+def _mixture_from(sk, g):
+    m = sk.Mixture()
+    m.w, m.mu, m.invcov = g["w"].copy(), g["mu"].copy(), g["invcov"].copy()
+    m.cov_var_ctl = 1.0 / m.invcov
+    m._compute_all()
+    return m
+
+
+@pytest.mark.parametrize("tag", ["c8_d6", "c40_d13"])
+def test_log_posterior_matrix_vs_reference_golden(sk, tag):
+    """Mixture.compute_log_posterior_probabilities (mixture.py:461-487): the T x C matrix itself.
+    float32 logits: absolute error scales with the magnitude of the quadratic form, so the bound is
+    1e-5 of the largest |lp| (well inside what 1e-4-relative posteriors need near the row maximum)."""
+    g = golden("estep_%s.npz" % tag)
+    m = _mixture_from(sk, g)
+    lp = m.compute_log_posterior_probabilities(g["cep"])
+    assert lp.shape == g["lp"].shape and lp.dtype == np.float64
+    assert np.abs(lp - g["lp"]).max() <= 1e-5 * np.abs(g["lp"]).max()
+    # posteriors from it agree with the reference's to 1e-4 relative on entries that matter
+    pp = np.exp(lp - g["log_lk"][:, None])
+    big = g["pp"] > 1e-3
+    assert (np.abs(pp - g["pp"])[big] / g["pp"][big]).max() < TOL
+
+
+@pytest.mark.parametrize("C,D,T", [(64, 60, 1000), (130, 20, 333), (2048, 60, 300), (1, 7, 50)])
+def test_log_posterior_matrix_mu_override(sk, C, D, T):
+    """`mu=` (MAP-adapted means, gmm_scoring.py:102-111) against the oracle; single-row input too."""
+    gmm = orc.random_gmm(C, D, seed=5)
+    cep = orc.synth_frames(T, D, seed=6)
+    m = sk.Mixture()
+    m.w, m.mu, m.invcov = gmm.w.copy(), gmm.mu.copy(), gmm.invcov.copy()
+    m.cov_var_ctl = 1.0 / m.invcov
+    m._compute_all()
+    mu2 = gmm.mu + 0.1 * np.random.RandomState(3).randn(C, D)
+    for mu in (None, mu2, mu2.reshape(-1)):
+        ref = orc.log_posterior(gmm, cep, mu=mu)
+        lp = m.compute_log_posterior_probabilities(cep, mu=mu)
+        assert lp.shape == (T, C)
+        assert np.abs(lp - ref).max() <= 1e-5 * np.abs(ref).max()
+    one = m.compute_log_posterior_probabilities(cep[0])
+    assert one.shape == (1, C)
+    assert np.abs(one - orc.log_posterior(gmm, cep[:1])).max() <= 1e-5 * np.abs(ref).max()

@@ -193,3 +193,17 @@ def test_total_variability_dropin_vs_reference_golden(sk, tmp_path):
     assert min_cosine(ivs2.stat1, g["iv_single"]) > 0.9999
     assert rel(ivs2.stat1, g["iv_single"]) < 2e-5
     assert rel(sig2, g["iv_sigma_single"]) < 2e-5
+
+    # total_variability_raw (factor_analyser.py:326-428): float64 whitening of an in-memory StatServer;
+    # SURVEY 8c measured it 5e-8 relative from _single on the reference itself, so the _single golden pins it
+    ss3 = sk.StatServer(stat_file)
+    before = ss3.stat1.copy()
+    fa4 = sk.FactorAnalyser()
+    fa4.total_variability_raw(ss3, ubm, 6, nb_iter=1, min_div=True, tv_init=g["tv_init"].copy(),
+                              output_file_name=str(tmp_path / "tvraw"))
+    assert rel(fa4.F, g["F_it1"]) < 1e-4
+    assert os.path.exists(str(tmp_path / "tvraw") + sk.FactorAnalyser._ext())
+    assert not np.allclose(ss3.stat1, before)      # left whitened, like the reference
+    np.testing.assert_allclose(ss3.stat1, orc.whiten_stat1(ss3.stat0, before, ubm.get_mean_super_vector(),
+                                                           1. / ubm.get_invcov_super_vector()),
+                               rtol=1e-12, atol=1e-12)
