@@ -182,6 +182,44 @@ __device__ __forceinline__ void stage_tile(float *xs, const float *__restrict__ 
     }
 }
 
+// Register-staged variant for 16-byte-aligned rows with D <= 64: the tile's 32*D/4 float4 elements are
+// requested SKM_PF_REGS per lane ahead of time (tile_prefetch) and written to LDS one tile later
+// (tile_commit), so the HBM latency of tile i+1 is covered by the MFMAs of tile i.
+#define SKM_PF_REGS 8
+__device__ __forceinline__ bool tile_prefetchable(const TileGeom &g) { return g.vec4 && g.D <= 64; }
+
+__device__ __forceinline__ void tile_prefetch(f32x4 (&pf)[SKM_PF_REGS], const float *__restrict__ X, long t0,
+                                              int nvalid, const TileGeom &g, int lane)
+{
+    const int n4 = g.D >> 2, total = 32 * n4;
+    const f32x4 *X4 = reinterpret_cast<const f32x4 *>(X + t0 * (long)g.D);
+    const int lim = nvalid * n4;   // elements of the valid rows (rows are contiguous)
+#pragma unroll
+    for (int i = 0; i < SKM_PF_REGS; ++i) {
+        const int e = lane + 64 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (e < total && e < lim) v = X4[e];
+        pf[i] = v;
+    }
+}
+
+__device__ __forceinline__ void tile_commit(float *xs, const f32x4 (&pf)[SKM_PF_REGS], const TileGeom &g, int lane)
+{
+    const int n4 = g.D >> 2, total = 32 * n4;
+    int row = lane / n4, c4 = lane - row * n4;
+    const int rstep = 64 / n4, cstep = 64 - rstep * n4;
+#pragma unroll
+    for (int i = 0; i < SKM_PF_REGS; ++i) {
+        if (lane + 64 * i < total) *reinterpret_cast<f32x4 *>(xs + row * g.XS + 4 * c4) = pf[i];
+        row += rstep;
+        c4 += cstep;
+        if (c4 >= n4) {
+            c4 -= n4;
+            row++;
+        }
+    }
+}
+
 // Order LDS traffic of ONE wave: DS operations of a wave execute in issue order, so only the
 // compiler has to be kept from moving reads above the writes of other lanes.
 __device__ __forceinline__ void wave_lds_fence()
@@ -336,6 +374,19 @@ __device__ __forceinline__ void lane_reduce16(float (&v)[16], int c, Op op)
 // ------------------------------------------------------------------------------------------------
 // sweep 1: per (component block, frame) partial max / sum of exp2
 // ------------------------------------------------------------------------------------------------
+#ifdef SKM_TRACE
+static long long *g_trace = nullptr;
+extern "C" void skm_trace_buffer(void *p) { g_trace = static_cast<long long *>(p); }
+#define SKM_TRACE_DECL bool trace_now = false
+#define SKM_TRACE_TILE trace_now = a.trace && blockIdx.x == 1 && lane == 0 && tile - ta == 40
+#define SKM_STAMP(k) \
+    if (trace_now) a.trace[wave * 16 + (k)] = __builtin_readcyclecounter()
+#else
+#define SKM_TRACE_DECL
+#define SKM_TRACE_TILE
+#define SKM_STAMP(k)
+#endif
+
 struct LseArgs {
     const float *X;
     long T;
@@ -347,6 +398,9 @@ struct LseArgs {
     int n_cb, n_fs;
     double *lp;       // optional [T][C] natural-log weighted component densities (NULL: not written)
     int C;
+#ifdef SKM_TRACE
+    long long *trace;
+#endif
 };
 
 template <int NCT>
@@ -381,10 +435,24 @@ __global__ __launch_bounds__(512, 2) void k_lse_partial(LseArgs a)
     float *pm = a.pm + (long)cb * a.T;
     float *ps = a.ps + (long)cb * a.T;
 
+    const bool pfok = tile_prefetchable(g);
+    f32x4 pf[SKM_PF_REGS];
+    if (pfok && ta < tb) tile_prefetch(pf, a.X, ta << 5, (int)((a.T - (ta << 5)) < 32 ? (a.T - (ta << 5)) : 32), g, lane);
+    SKM_TRACE_DECL;
     for (long tile = ta; tile < tb; ++tile) {
         const long t0 = tile << 5;
         const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
-        stage_tile(xs, a.X, t0, nvalid, g, lane);
+        SKM_TRACE_TILE;
+        SKM_STAMP(0);
+        if (pfok) {
+            tile_commit(xs, pf, g, lane);
+            if (tile + 1 < tb) {
+                const long t1 = t0 + 32;
+                tile_prefetch(pf, a.X, t1, (int)((a.T - t1) < 32 ? (a.T - t1) : 32), g, lane);
+            }
+        } else {
+            stage_tile(xs, a.X, t0, nvalid, g, lane);
+        }
         wave_lds_fence();
 
         f32x16 lg[NCT];
@@ -393,7 +461,9 @@ __global__ __launch_bounds__(512, 2) void k_lse_partial(LseArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) lg[ct][r] = kcv[ct];
 
+        SKM_STAMP(1);
         gemm_logits<NCT>(lg, xs + c * g.XS, h, Wl4, g);
+        SKM_STAMP(2);
 
         if (a.lp) {
             // lp[t][c] = ln(w_c N(x_t; c)): a row of 32 consecutive components per register
@@ -408,17 +478,39 @@ __global__ __launch_bounds__(512, 2) void k_lse_partial(LseArgs a)
                 }
             }
         }
-        // Row (= frame) logsumexp over the 32 component lanes of each half and the NCT tiles.
-        float mym, mys;
-        wave_lse_reduce<NCT>(lg, c, mym, mys);
-        if ((c & 1) == 0) {
-            const int frame = acc_row((c >> 1) & 15, h);
-            if (frame < nvalid) {
-                pm[t0 + frame] = mym;
-                ps[t0 + frame] = mys;
+        // Row (= frame) maximum and sum of 2^(l - max) over this block's NCT * 32 components: exact maximum
+        // first (DPP butterfly), broadcast through the wave's LDS row, one exponential per logit.
+        float m[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            m[r] = lg[0][r];
+#pragma unroll
+            for (int ct = 1; ct < NCT; ++ct) m[r] = __builtin_fmaxf(m[r], lg[ct][r]);
+        }
+        lane_reduce16(m, c, OpMax());
+        const int frame = acc_row((c >> 1) & 15, h);
+        float *mrow = xs + 32 * g.XS;   // 32 floats behind the wave's tile
+        if ((c & 1) == 0) mrow[frame] = m[0];
+        wave_lds_fence();
+        float sm[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 m4 = *reinterpret_cast<const f32x4 *>(mrow + 8 * q4 + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float acc1 = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc1 += __builtin_amdgcn_exp2f(lg[ct][4 * q4 + i] - m4[i]);
+                sm[4 * q4 + i] = acc1;
             }
         }
+        lane_reduce16(sm, c, OpAdd());
+        if ((c & 1) == 0 && frame < nvalid) {
+            pm[t0 + frame] = m[0];
+            ps[t0 + frame] = sm[0];
+        }
         wave_lds_fence();  // all reads of xs done before the next tile is staged
+        SKM_STAMP(3);
     }
 }
 
@@ -682,18 +774,7 @@ struct FusedArgs {
     long long *trace;  // [NWV][16] cycle stamps of one tile of block 1 (tools/trace_estep.py)
 #endif
 };
-#ifdef SKM_TRACE
-static long long *g_trace = nullptr;
-extern "C" void skm_trace_buffer(void *p) { g_trace = static_cast<long long *>(p); }
-#define SKM_TRACE_DECL bool trace_now = false
-#define SKM_TRACE_TILE trace_now = a.trace && blockIdx.x == 1 && lane == 0 && tile - ta == 40
-#define SKM_STAMP(k) \
-    if (trace_now) a.trace[wave * 16 + (k)] = __builtin_readcyclecounter()
-#else
-#define SKM_TRACE_DECL
-#define SKM_TRACE_TILE
-#define SKM_STAMP(k)
-#endif
+
 
 template <int NJT>
 __global__ __launch_bounds__(512, 2) void k_estep_fused(FusedArgs a)
@@ -977,6 +1058,492 @@ __global__ __launch_bounds__(512, 2) void k_estep_fused(FusedArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Single-sweep E-step, one wave per SIMD.  Measured on gfx950 (tools/ubench/mfma_valu_mix.hip): a VALU
+// instruction issued between two f32 MFMAs of the SAME wave costs ~2.5-3 matrix-pipe cycles (the f32 MFMA
+// shares the FP32 datapath), and a second wave on the SIMD only gets one VALU issue per ~12 cycles while its
+// partner streams MFMAs.  So instead of two 256-register waves per SIMD that fight over the issue port,
+// this kernel runs ONE 512-register wave per SIMD that owns NCT = 4 component tiles: the per-tile
+// logsumexp work (two lane butterflies, the cross-wave combine) is paid once per 128 components instead
+// of once per 64 and runs at the full VALU rate, and the register file has room to request the W
+// fragments of the next pair (32 registers) while the 32 MFMAs of the current pair issue.
+// ------------------------------------------------------------------------------------------------
+// The statistics accumulators of the one-wave kernel fill the 256 AGPRs exactly.  hipcc 7.2 left to itself
+// parks them in VGPRs and shuttles them through AGPRs and scratch every tile, so these MFMAs are written
+// with an explicit "a" (AGPR) constraint.  Hazards the compiler cannot see inside an asm block are covered
+// by hand: `s_nop 1` where a B operand was just produced by a VALU instruction, and agpr_settle() before the
+// accumulators are read back.
+__device__ __forceinline__ void mfma_agpr(f32x16 &acc, float a, float b)
+{
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_agpr_after_valu(f32x16 &acc, float a, float b)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// logits accumulators stay in VGPRs (a builtin MFMA in this kernel makes the allocator claim AGPRs for its
+// result and evict the statistics accumulators every tile)
+__device__ __forceinline__ void mfma_vgpr(f32x16 &acc, float a, float b)
+{
+#ifdef SKM_FAT_BUILTIN
+    acc = SKM_MFMA32(a, b, acc);
+    return;
+#endif
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_vgpr_after_valu(f32x16 &acc, float a, float b)
+{
+#ifdef SKM_FAT_BUILTIN
+    acc = SKM_MFMA32(a, b, acc);
+    return;
+#endif
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// VALU write -> MFMA read of the same VGPRs needs 2 wait states the compiler cannot place for an asm MFMA
+__device__ __forceinline__ void valu_to_mfma(f32x16 &v)
+{
+    asm volatile("s_nop 3" : "+v"(v));
+}
+__device__ __forceinline__ void vgpr_settle(f32x16 &acc)
+{
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc));
+}
+__device__ __forceinline__ void agpr_settle(f32x16 &acc)
+{
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc));
+}
+
+template <int NCT>
+struct WSet {
+    f32x4 l[NCT], q[NCT];
+};
+
+// W fragments are fetched with buffer loads: one per-lane VGPR offset (lane * 16) for every load, the group
+// address is a scalar offset, so the stream costs no vector instructions for addressing and no address
+// registers (a flat-address version kept 120 64-bit pointers alive and spilled them).
+struct WStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;    // lane * 16
+    int sbase;   // byte offset of this wave's first component tile
+};
+
+template <int NCT>
+__device__ __forceinline__ void wset_load(WSet<NCT> &w, const WStream &ws, int NG, int NP, int k)
+{
+    // pair k: linear group 2k, square group 2k+1; k == NP names the mixed tail group
+    const int gl = (k < NP) ? 2 * k : NG - 1, gq = (k < NP) ? 2 * k + 1 : NG - 1;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        w.l[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff,
+                                                                                  ws.sbase + (ct * NG + gl) * 1024, 0));
+        w.q[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff,
+                                                                                  ws.sbase + (ct * NG + gq) * 1024, 0));
+    }
+}
+
+__device__ __forceinline__ f32x4 wfrag_load(const WStream &ws, int soff)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, ws.sbase + soff, 0));
+}
+
+// 8 * NCT MFMAs of pair `cur` on the tile row a4, with the 2 * NCT fragment loads of set `knext` spread
+// between them (one load behind every 4 MFMAs: a single wave issues in order, so a cluster of loads and
+// their scalar address arithmetic between two MFMA groups leaves the matrix pipe idle for ~300 cycles).
+// All 8 MFMAs of one accumulator run back to back.
+template <int NCT>
+__device__ __forceinline__ void wset_mma_pf(f32x16 (&lg)[NCT], const WSet<NCT> &cur, const f32x4 a4, WSet<NCT> &nxt,
+                                            const WStream &ws, int NG, int NP, int knext)
+{
+    f32x4 s4 = a4 * a4;
+    asm volatile("s_nop 1" : "+v"(s4));
+    const int gl = (knext < NP) ? 2 * knext : NG - 1, gq = (knext < NP) ? 2 * knext + 1 : NG - 1;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mfma_vgpr(lg[ct], a4[i], cur.l[ct][i]);
+        nxt.l[ct] = wfrag_load(ws, (ct * NG + gl) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mfma_vgpr(lg[ct], s4[i], cur.q[ct][i]);
+        nxt.q[ct] = wfrag_load(ws, (ct * NG + gq) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// one settle for all accumulators: only the last MFMA can still be in flight (each earlier one issued >= 64
+// cycles before it); 20 wait states cover the 18 a 16-pass MFMA needs before a VALU may read its result
+template <int NCT>
+__device__ __forceinline__ void vgpr_settle_all(f32x16 (&lg)[NCT])
+{
+    static_assert(NCT == 4, "operand list is written for four accumulators");
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lg[0]), "+v"(lg[1]), "+v"(lg[2]), "+v"(lg[3]));
+}
+
+// mixed tail group (held in wl) with the loads of pair 0 for the next tile spread between the MFMAs.
+// Branch-free, and the results are settled before the function returns: wherever control flow merges
+// behind asm MFMAs the compiler places register copies that would read the accumulators too early.
+template <int NCT, bool TAIL>
+__device__ __forceinline__ void wset_tail_pf(f32x16 (&lg)[NCT], const f32x4 (&wl)[NCT], f32x4 xt, WSet<NCT> &nxt,
+                                             const WStream &ws, int NG)
+{
+    asm volatile("s_nop 1" : "+v"(xt));
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        if (TAIL) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mfma_vgpr(lg[ct], xt[i], wl[ct][i]);
+        }
+        nxt.l[ct] = wfrag_load(ws, (ct * NG) * 1024);
+        nxt.q[ct] = wfrag_load(ws, (ct * NG + 1) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    vgpr_settle_all<NCT>(lg);
+}
+
+// lg += [x, x^2] . W with W streamed from L2; `wa` must already hold pair 0 on entry (requested during the
+// previous tile) and holds pair 0 again on return.
+template <int NCT>
+__device__ __forceinline__ void gemm_logits_fat(f32x16 (&lg)[NCT], WSet<NCT> &wa, const float *xs_row, int h,
+                                                const WStream &Wg4, const TileGeom &g, long long *tr = nullptr)
+{
+    const float *xr = xs_row + 4 * h;
+    const int NG = g.NG, NP = g.NP;
+    WSet<NCT> wb;
+    f32x4 xa = *reinterpret_cast<const f32x4 *>(xr), xb;
+    f32x4 xt = *reinterpret_cast<const f32x4 *>(xs_row + 8 * NP);
+    if (h) xt = xt * xt;
+    int q = 0;
+#ifdef SKM_TRACE
+    if (tr) tr[8] = __builtin_readcyclecounter();
+#endif
+    for (; q + 2 <= NP; q += 2) {
+#ifdef SKM_TRACE
+        if (tr && q == 2) tr[9] = __builtin_readcyclecounter();
+        if (tr && q == 4) tr[10] = __builtin_readcyclecounter();
+#endif
+        xb = *reinterpret_cast<const f32x4 *>(xr + 8 * (q + 1));
+        wset_mma_pf<NCT>(lg, wa, xa, wb, Wg4, NG, NP, q + 1);
+        xa = *reinterpret_cast<const f32x4 *>(xr + 8 * ((q + 2 < NP) ? q + 2 : 0));
+        wset_mma_pf<NCT>(lg, wb, xb, wa, Wg4, NG, NP, q + 2);   // q + 2 == NP: the tail group
+    }
+    vgpr_settle_all<NCT>(lg);   // the blocks below may start with copies of lg
+#ifdef SKM_TRACE
+    if (tr) tr[11] = __builtin_readcyclecounter();
+#endif
+    if (q < NP) {   // odd pair count: pair q sits in wa, the tail group goes to wb
+        wset_mma_pf<NCT>(lg, wa, xa, wb, Wg4, NG, NP, q + 1);
+        if (g.tail)
+            wset_tail_pf<NCT, true>(lg, wb.l, xt, wa, Wg4, NG);
+        else
+            wset_tail_pf<NCT, false>(lg, wb.l, xt, wa, Wg4, NG);
+    } else {        // even pair count: wa holds the tail group
+        WSet<NCT> w0;
+        if (g.tail)
+            wset_tail_pf<NCT, true>(lg, wa.l, xt, w0, Wg4, NG);
+        else
+            wset_tail_pf<NCT, false>(lg, wa.l, xt, w0, Wg4, NG);
+        wa = w0;
+    }
+}
+
+template <int NJT, int NCT>
+__device__ __forceinline__ void gemm_stats_agpr(f32x16 (&acc)[NCT][2 * NJT], const f32x16 (&lg)[NCT],
+                                                const float *xcol, int XS)
+{
+    float bn[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) bn[jt] = xcol[jt * 32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float b[NJT], b2[NJT];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            b[jt] = bn[jt];
+            b2[jt] = b[jt] * b[jt];
+        }
+        if (r < 15) {
+            const float *xrow = xcol + acc_row(r + 1, 0) * XS;
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) bn[jt] = xrow[jt * 32];
+        }
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) mfma_agpr(acc[ct][jt], lg[ct][r], b[jt]);
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                if (ct == 0)
+                    mfma_agpr_after_valu(acc[ct][NJT + jt], lg[ct][r], b2[jt]);
+                else
+                    mfma_agpr(acc[ct][NJT + jt], lg[ct][r], b2[jt]);
+            }
+    }
+}
+
+template <int NCT, int NF>
+__device__ __forceinline__ void flush_slab_agpr(f32x16 (&acc)[NCT][NF], double *slab_lane)
+{
+    constexpr int NFW = NF * 32;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int jf = 0; jf < NF; ++jf) {
+            agpr_settle(acc[ct][jf]);
+            double *p = slab_lane + ct * 32 * NFW + jf * 32;
+            const f32x16 v = acc[ct][jf];
+            double old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = p[acc_row(r, 0) * NFW];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[acc_row(r, 0) * NFW] = old[r] + (double)v[r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+template <int NCT, int NJT>
+__global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
+{
+    constexpr int NF = 2 * NJT, NFW = NF * 32, PRE = 8;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, NWV = nthr >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const TileGeom g = a.g;
+    const int tile_floats = 32 * g.XS;
+
+    float *xs = smem;                                // [3][32][XS]
+    float *partm = xs + 3 * tile_floats;             // [2][NWV][32]
+    float *parts = partm + 2 * NWV * 32;             // [2][NWV][32]
+    float *ls = parts + 2 * NWV * 32 + wave * 32;    // wave-private row of 32
+
+    {
+        const int padw = g.XS - g.D;
+        for (int i = tid; i < 3 * 32 * padw; i += nthr) {
+            const int row = i / padw, col = g.D + (i - row * padw);
+            xs[row * g.XS + col] = (col == g.D) ? 1.0f : 0.0f;
+        }
+    }
+    float kcv[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) kcv[ct] = a.kc[(wave * NCT + ct) * 32 + c];
+    WStream Wg4;
+    Wg4.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp), 0, NWV * NCT * g.NG * 1024, 0x00027000);
+    Wg4.voff = lane * 16;
+    Wg4.sbase = __builtin_amdgcn_readfirstlane(wave) * (NCT * g.NG * 1024);
+
+    f32x16 acc[NCT][NF];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int jf = 0; jf < NF; ++jf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
+
+    const long tiles = (a.T + 31) >> 5;
+    const long ta = tiles * blockIdx.x / gridDim.x, tb = tiles * (blockIdx.x + 1) / gridDim.x;
+    double *slab_lane = a.slabs + ((long)blockIdx.x * NWV + wave) * (long)(NCT * 32 * NFW) + (4 * h) * NFW + c;
+    double llk_lane = 0.0;
+
+    // cooperative staging of the contiguous 32*D span of a tile: PRE floats per thread (the host only selects
+    // this kernel when 32*D <= PRE*nthr); source / destination offsets are fixed per thread
+    constexpr int NST = PRE / 4;
+    float pre[PRE];
+    int st_src[NST], st_dst[NST], st_row[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        // vec4: element = float4 index; scalar geometry: elements are handled 4 consecutive floats per slot
+        const int e = tid + i * nthr;
+        if (g.vec4) {
+            const int n4 = g.D >> 2;
+            const int row = e / n4;
+            st_src[i] = e;
+            st_row[i] = (e < 32 * n4) ? row : 1 << 20;
+            st_dst[i] = row * g.XS + 4 * (e - row * n4);
+        } else {
+            st_src[i] = e;
+            st_row[i] = 0;
+            st_dst[i] = 0;
+        }
+    }
+    auto load_pre = [&](long t0, int nvalid) __attribute__((always_inline)) {
+        if (g.vec4) {
+            const f32x4 *X4 = reinterpret_cast<const f32x4 *>(a.X + t0 * (long)g.D);
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (st_row[i] < nvalid) v = X4[st_src[i]];
+                pre[4 * i + 0] = v[0];
+                pre[4 * i + 1] = v[1];
+                pre[4 * i + 2] = v[2];
+                pre[4 * i + 3] = v[3];
+            }
+        } else {
+            const float *Xs = a.X + t0 * (long)g.D;
+            const int n_el = 32 * g.D;
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) {
+                const int e = tid + i * nthr;
+                pre[i] = (e < n_el && e / g.D < nvalid) ? Xs[e] : 0.f;
+            }
+        }
+    };
+    auto store_pre = [&](float *dst) __attribute__((always_inline)) {
+        if (g.vec4) {
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                if (st_row[i] < 32) {
+                    f32x4 v = {pre[4 * i], pre[4 * i + 1], pre[4 * i + 2], pre[4 * i + 3]};
+                    *reinterpret_cast<f32x4 *>(dst + st_dst[i]) = v;
+                }
+            }
+        } else {
+            const int n_el = 32 * g.D;
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) {
+                const int e = tid + i * nthr;
+                if (e < n_el) {
+                    const int row = e / g.D;
+                    dst[row * g.XS + (e - row * g.D)] = pre[i];
+                }
+            }
+        }
+    };
+
+    if (ta < tb) {
+        const long t0 = ta << 5;
+        load_pre(t0, (int)((a.T - t0) < 32 ? (a.T - t0) : 32));
+        store_pre(xs);
+        if (ta + 1 < tb) load_pre(t0 + 32, (int)((a.T - t0 - 32) < 32 ? (a.T - t0 - 32) : 32));
+    }
+    WSet<NCT> wa;
+    wset_load<NCT>(wa, Wg4, g.NG, g.NP, 0);
+    __syncthreads();
+
+    SKM_TRACE_DECL;
+    int cur = 0;
+    for (long base = ta; base < tb; base += SKM_FLUSH_TILES) {
+    const long end = (base + SKM_FLUSH_TILES < tb) ? base + SKM_FLUSH_TILES : tb;
+#pragma unroll 1
+    for (long tile = base; tile < end; ++tile) {
+        const long t0 = tile << 5;
+        const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
+        const int nxt = (cur == 2) ? 0 : cur + 1;
+        const int pslot = (int)((tile - ta) & 1);
+        const bool has_next = tile + 1 < tb;
+        SKM_TRACE_TILE;
+        SKM_STAMP(0);
+        const float *xt = xs + cur * tile_floats;
+
+        f32x16 lg[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            // opaque per tile: otherwise the 64-register splat is hoisted out of the loop, spilled, and
+            // reloaded from scratch in front of every tile's first MFMA
+            float k = kcv[ct];
+            asm volatile("" : "+v"(k));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lg[ct][r] = k;
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
+#ifdef SKM_TRACE
+        gemm_logits_fat<NCT>(lg, wa, xt + c * g.XS, h, Wg4, g, trace_now ? a.trace + wave * 16 : nullptr);
+#else
+        gemm_logits_fat<NCT>(lg, wa, xt + c * g.XS, h, Wg4, g);
+#endif
+        SKM_STAMP(1);
+
+        // exact per-frame maximum over this wave's NCT*32 components, e = 2^(l - max), per-frame sum of e
+        float m[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            m[r] = lg[0][r];
+#pragma unroll
+            for (int ct = 1; ct < NCT; ++ct) m[r] = __builtin_fmaxf(m[r], lg[ct][r]);
+        }
+        lane_reduce16(m, c, OpMax());
+        const int frame = acc_row((c >> 1) & 15, h);
+        if ((c & 1) == 0) ls[frame] = m[0];
+        wave_lds_fence();
+        float sm[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float acc1 = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const float e = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + i] - m4[i]);
+                    lg[ct][4 * q4 + i] = e;
+                    acc1 += e;
+                }
+                sm[4 * q4 + i] = acc1;
+            }
+        }
+        lane_reduce16(sm, c, OpAdd());
+        if ((c & 1) == 0) {
+            partm[(pslot * NWV + wave) * 32 + frame] = m[0];
+            parts[(pslot * NWV + wave) * 32 + frame] = sm[0];
+        }
+        SKM_STAMP(2);
+        // next tile goes to the buffer last read two tiles ago (every wave is past that tile's barrier)
+        if (has_next) store_pre(xs + nxt * tile_floats);
+        SKM_STAMP(3);
+        __syncthreads();
+        SKM_STAMP(4);
+        {
+            const float *pmv = partm + pslot * NWV * 32 + c;
+            const float *psv = parts + pslot * NWV * 32 + c;
+            float mx = pmv[0];
+            for (int w = 1; w < NWV; ++w) mx = __builtin_fmaxf(mx, pmv[w * 32]);
+            float sum = 0.f;
+            for (int w = 0; w < NWV; ++w) sum += psv[w * 32] * __builtin_amdgcn_exp2f(pmv[w * 32] - mx);
+            const bool valid = c < nvalid;
+            const float f = __builtin_amdgcn_exp2f(pmv[wave * 32] - mx) * __builtin_amdgcn_rcpf(sum);
+            if (h == 0) ls[c] = valid ? f : 0.f;
+            if (wave == 0 && h == 0 && valid) llk_lane += (double)(mx + __builtin_amdgcn_logf(sum));
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 f4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                lg[ct][4 * q4 + 0] *= f4[0];
+                lg[ct][4 * q4 + 1] *= f4[1];
+                lg[ct][4 * q4 + 2] *= f4[2];
+                lg[ct][4 * q4 + 3] *= f4[3];
+            }
+        }
+        // frames of tile+2 are requested here: the statistics GEMM that follows has no other vector-memory
+        // wait, so the HBM latency never sits in front of an in-order vmcnt wait of the W stream
+        if (tile + 2 < tb) {
+            const long t2 = (tile + 2) << 5;
+            load_pre(t2, (int)((a.T - t2) < 32 ? (a.T - t2) : 32));
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
+        SKM_STAMP(5);
+        gemm_stats_agpr<NJT, NCT>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
+        SKM_STAMP(6);
+        wave_lds_fence();
+        cur = nxt;
+    }
+    // the accumulators are touched by nothing but the asm MFMAs inside the tile loop, so they stay in AGPRs
+    flush_slab_agpr<NCT, NF>(acc, slab_lane);
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int msk = 1; msk < 32; msk <<= 1) llk_lane += __shfl_xor(llk_lane, msk);
+        if (lane == 0) a.llk_part[blockIdx.x] = llk_lane * 0.6931471805599453094;
+    }
+}
+
 // Sum the per-wave f64 slabs in a fixed order into out = [N | F | S | llk].
 __global__ __launch_bounds__(256) void k_reduce_slabs(const double *__restrict__ slabs, int n_cb, int n_fs, int NW,
                                                       int NCT, int NJT, int NF, int C, int D,
@@ -1126,7 +1693,7 @@ struct Plan {
     size_t lds2;
     int n_llk;
     // single-sweep kernel (7..16 component tiles, D <= 63)
-    int fused, fused_nwv, fused_blocks;
+    int fused, fused_nwv, fused_blocks, fused_fat, fat_blocks;
     size_t fused_lds;
     // workspace offsets (bytes)
     size_t off_pm, off_ps, off_lse, off_llk, off_slabs, total;
@@ -1188,6 +1755,15 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
     p->fused_nwv = (g.CT + 1) / 2;
     p->fused_blocks = wgs * (p->fused_nwv <= 4 ? 2 : 1);
     if (p->fused_blocks > p->n_llk) p->fused_blocks = p->n_llk;
+    // one 512-register wave per SIMD with 4 component tiles each; staging needs 32*D <= 8 floats * threads
+    {
+        const int fw = g.CTpad / 4;
+        const char *e = getenv("SKM_FAT");
+        // 3 waves would leave one SIMD of the CU idle (a 512-register wave owns its SIMD): 2 or 4 only
+        p->fused_fat = (p->fused && (fw == 2 || fw == 4) && 32 * g.D <= 8 * 64 * fw && (e ? atoi(e) != 0 : 1)) ? 1 : 0;
+        p->fat_blocks = wgs * (fw <= 2 ? 2 : 1);
+        if (p->fat_blocks > p->n_llk) p->fat_blocks = p->n_llk;
+    }
     p->fused_lds = ((size_t)3 * 32 * g.XS + (size_t)4 * p->fused_nwv * 32 + (size_t)p->fused_nwv * 32 +
                     (size_t)p->fused_nwv * 2 * 16 * 64) * sizeof(float);
     size_t off = 0;
@@ -1208,7 +1784,9 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         const int ncb = (g.CT + nct - 1) / nct;
         const int nfs = wgs / ncb > 0 ? wgs / ncb : 1;
         size_t sl = (size_t)ncb * nfs * nw * nct * 32 * nf * 32 * sizeof(double);
-        const size_t slf = (size_t)p->fused_blocks * p->fused_nwv * 64 * nf * 32 * sizeof(double);
+        size_t slf = (size_t)p->fused_blocks * p->fused_nwv * 64 * nf * 32 * sizeof(double);
+        const size_t slfat = (size_t)p->fat_blocks * (g.CTpad / 4) * 128 * nf * 32 * sizeof(double);
+        if (p->fused_fat && slfat > slf) slf = slfat;
         if (p->fused && slf > sl) sl = slf;
         off += skm_align_up(sl, 256);
     }
@@ -1238,6 +1816,9 @@ static int launch_lse(SkmCtx *ctx, const Plan &p, const float *X, long T, const 
     LseArgs a;
     a.lp = lp;
     a.C = C;
+#ifdef SKM_TRACE
+    a.trace = g_trace;
+#endif
     a.X = X;
     a.T = T;
     a.g = p.tg;
@@ -1357,12 +1938,21 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
             const char *e = getenv("SKM_STAGGER");
             f.stagger = e ? atoi(e) : 1;
         }
-        const int nwv = p.fused_nwv, nblk = p.fused_blocks, nf = 2 * p.g.NJT;
-        SKM_HIP(hipMemsetAsync(f.slabs, 0, (size_t)nblk * nwv * 64 * nf * 32 * sizeof(double), st));
+        const bool fat = p.fused_fat;
+        const int nwv = fat ? p.g.CTpad / 4 : p.fused_nwv, nblk = fat ? p.fat_blocks : p.fused_blocks, nf = 2 * p.g.NJT;
+        SKM_HIP(hipMemsetAsync(f.slabs, 0, (size_t)nblk * nwv * (fat ? 128 : 64) * nf * 32 * sizeof(double), st));
         SKM_HIP(hipMemsetAsync(f.llk_part, 0, p.n_llk * sizeof(double), st));
         {
             SkmProfScope ps(ctx, "k_estep_fused", st);
-            if (p.g.NJT == 1) {
+            if (fat) {
+                if (p.g.NJT == 1) {
+                    if ((rc = set_lds(k_estep_fat<4, 1>, p.fused_lds))) return rc;
+                    hipLaunchKernelGGL((k_estep_fat<4, 1>), dim3(nblk), dim3(64 * nwv), p.fused_lds, st, f);
+                } else {
+                    if ((rc = set_lds(k_estep_fat<4, 2>, p.fused_lds))) return rc;
+                    hipLaunchKernelGGL((k_estep_fat<4, 2>), dim3(nblk), dim3(64 * nwv), p.fused_lds, st, f);
+                }
+            } else if (p.g.NJT == 1) {
                 if ((rc = set_lds(k_estep_fused<1>, p.fused_lds))) return rc;
                 hipLaunchKernelGGL(k_estep_fused<1>, dim3(nblk), dim3(64 * nwv), p.fused_lds, st, f);
             } else {
@@ -1374,7 +1964,7 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
         const long n_out = (long)C * nf * 32;
         SkmProfScope ps(ctx, "k_reduce_slabs", st);
         hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, f.slabs, nwv, nblk,
-                           1, 2, p.g.NJT, nf, C, D, out, accumulate, f.llk_part, p.n_llk);
+                           1, fat ? 4 : 2, p.g.NJT, nf, C, D, out, accumulate, f.llk_part, p.n_llk);
         SKM_HIP(hipGetLastError());
         return SKM_OK;
     }

@@ -19,8 +19,8 @@ eng.estep(X, packed)
 torch.cuda.synchronize()
 t = buf.cpu().numpy().reshape(8, 16)
 base = t[t > 0].min()
-names = ["start", "logits", "lse_part", "staged", "bar/stash", "exp", "stats", "fence", "bar(late)"]
+names = ["start", "logits", "lse_part", "staged", "bar/stash", "exp", "stats", "fence", "bar(late)", "lg_q2", "lg_q4", "lg_loopend"]
 print("stagger", os.environ.get("SKM_STAGGER", "1"), " stamps relative to the earliest, cycles")
 print("wave " + " ".join("%10s" % n for n in names))
 for w in range(8):
-    print("%4d " % w + " ".join("%10d" % (t[w, k] - base if t[w, k] else -1) for k in range(9)))
+    print("%4d " % w + " ".join("%10d" % (t[w, k] - base if t[w, k] else -1) for k in range(len(names))))
