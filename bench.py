@@ -178,10 +178,12 @@ def main():
         eng.profile(False)
         kt = {k: v[1] / v[0] for k, v in prof.items()}            # avg ms per launch
         flop_path = 8.0 * D * C * T         # log-lik GEMM + statistics GEMM
-        if "k_estep_fused" in kt:
+        single = [k for k in ("k_estep_fat", "k_estep_fused") if k in kt]
+        if single:
             # single-sweep kernel (C <= 512): the whole E-step is one kernel, all 8*D*C*T flops are its own
-            dom, t_dom, flop_dom, issued = "k_estep_fused", kt["k_estep_fused"], flop_path, (4.0 * D + 4.0 * 64) * C * T
-            t_path = sum(kt.get(k, 0.0) for k in ("k_estep_fused", "k_reduce_slabs"))
+            dom = single[0]
+            t_dom, flop_dom, issued = kt[dom], flop_path, (4.0 * D + 4.0 * 64) * C * T
+            t_path = sum(kt.get(k, 0.0) for k in (dom, "k_reduce_slabs"))
         else:
             # two sweeps: the statistics GEMM gamma^T [x, x^2] is the algorithmic work of k_stats_em; the
             # logits it recomputes are NOT counted
@@ -204,6 +206,8 @@ def main():
                         result["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
                         result["roofline"]["traffic_source"] = "profiles/r1_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE)"
                         result["roofline"]["algorithmic_bytes_per_launch"] = 4.0 * D * T
+                        if "mfma_util" in rec:
+                            result["roofline"]["mfma_util_pmc"] = rec["mfma_util"]
         achp = flop_path / (t_path * 1e-3) / 1e12
         result["roofline_path"] = {"bound": "mfma", "kernels": {k: round(v, 4) for k, v in kt.items()},
                                    "achieved": achp, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -239,6 +243,32 @@ def main():
                                            "avg_launch_ms": t_bw},
                               "path_frac_of_mfma_peak": 6.0 * D * Cb * S * L / dtb / 1e12 / PEAK_F32_MFMA_TFLOPS}
         del s0, s1
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        # ---- EM iteration at the target size (BASELINE configs[2] per-GPU shape, fewer frames): C=2048
+        Ce, Te = 2048, min(T, 4_000_000)
+        ubm_e = random_ubm(sk, Ce, D, seed=11)
+        acc_e = copy.deepcopy(ubm_e)
+        Xe = X[:Te]
+        em_iteration(ubm_e, acc_e, Xe)
+        torch.cuda.synchronize()
+        eng.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            em_iteration(ubm_e, acc_e, Xe)
+        torch.cuda.synchronize()
+        dte = (time.perf_counter() - t0) / 2
+        prof = eng.profile_read()
+        eng.profile(False)
+        kte = {k: v[1] / v[0] for k, v in prof.items()}
+        t_k = sum(kte.values())
+        result["em_c2048"] = {"value": Te / dte, "unit": "frames/s", "ms_per_iteration": 1e3 * dte,
+                              "workload": "UBM EM iteration, C=%d, D=%d, %d frames" % (Ce, D, Te),
+                              "kernels_ms": {k: round(v, 3) for k, v in kte.items()},
+                              "roofline_path": {"bound": "mfma", "achieved": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12,
+                                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
+        del ubm_e, acc_e, Xe
 
     if rank == 0 and world == 1 and not args.no_extra:
         # ---- TV training iteration + i-vector extraction (BASELINE configs[4], fewer sessions): R=400, C=2048

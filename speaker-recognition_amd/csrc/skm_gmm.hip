@@ -1943,7 +1943,7 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
         SKM_HIP(hipMemsetAsync(f.slabs, 0, (size_t)nblk * nwv * (fat ? 128 : 64) * nf * 32 * sizeof(double), st));
         SKM_HIP(hipMemsetAsync(f.llk_part, 0, p.n_llk * sizeof(double), st));
         {
-            SkmProfScope ps(ctx, "k_estep_fused", st);
+            SkmProfScope ps(ctx, fat ? "k_estep_fat" : "k_estep_fused", st);
             if (fat) {
                 if (p.g.NJT == 1) {
                     if ((rc = set_lds(k_estep_fat<4, 1>, p.fused_lds))) return rc;
