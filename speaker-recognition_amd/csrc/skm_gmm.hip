@@ -1544,17 +1544,376 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Single-sweep E-step for C > 512: B = C/512 workgroups (a "team", one per CU, same XCD) cover the
+// components of the SAME frame tiles, each exactly like k_estep_fat (4 waves x 4 component tiles), and
+// exchange their per-frame (max, sum) partials through a small buffer in global memory instead of
+// recomputing the logits in a second sweep (124 instead of 184 MFMAs per 32x32 logits tile).
+//
+// Pipeline per workgroup, one tile late on the consumer side so the exchange latency never shows:
+//   iteration i:  logits(i) -> e = 2^(l - m_wave), publish (m_wave, s_wave) of tile i, stash e(i) in LDS
+//                 barrier (frame-tile ring only)
+//                 collect the 4*B partials of tile i-1 (published one whole logits phase ago),
+//                 gamma(i-1) = e(i-1) * 2^(m_wave - m) / s, statistics GEMM of tile i-1
+// Hand-off protocol (MI355X_MICROARCH.md, inter-workgroup visibility): every partial is stored and loaded
+// with agent-scope (sc1) accesses; the producer drains them (release fence) before it stores the flag
+// = tile sequence number; consumers poll the flags with agent-scope loads.  Four slots: a producer may be
+// two tiles ahead of the slowest consumer of its team.  The kernel is launched cooperatively (all
+// workgroups co-resident or the launch fails and the host falls back to two sweeps); every poll loop is
+// bounded and raises *err instead of spinning forever.
+// ------------------------------------------------------------------------------------------------
+template <int PRE>
+struct TileStager {
+    static constexpr int NST = PRE / 4;
+    float pre[PRE];
+    int src[NST], dst[NST], row[NST];
+    __device__ __forceinline__ void init(const TileGeom &g, int tid, int nthr)
+    {
+        const int n4 = g.D >> 2;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int e = tid + i * nthr, r = e / n4;
+            src[i] = e;
+            row[i] = (e < 32 * n4) ? r : 1 << 20;
+            dst[i] = r * g.XS + 4 * (e - r * n4);
+        }
+    }
+    __device__ __forceinline__ void load(const float *__restrict__ X, long t0, int nvalid, int D)
+    {
+        const f32x4 *X4 = reinterpret_cast<const f32x4 *>(X + t0 * (long)D);
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row[i] < nvalid) v = X4[src[i]];
+            pre[4 * i + 0] = v[0];
+            pre[4 * i + 1] = v[1];
+            pre[4 * i + 2] = v[2];
+            pre[4 * i + 3] = v[3];
+        }
+    }
+    __device__ __forceinline__ void store(float *xs_tile) const
+    {
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            if (row[i] < 32) {
+                const f32x4 v = {pre[4 * i], pre[4 * i + 1], pre[4 * i + 2], pre[4 * i + 3]};
+                *reinterpret_cast<f32x4 *>(xs_tile + dst[i]) = v;
+            }
+    }
+};
+
+struct TeamArgs {
+    const float *X;
+    long T;
+    TileGeom g;
+    const float *wp;
+    const float *kc;
+    double *slabs;        // [team][member][wave] slabs of [128][NF*32] f64 (zeroed by the host)
+    double *llk_part;     // [n_teams]
+    float *xch;           // [team][4 slots][4*B contributions][32 frames][2] (max, sum)
+    unsigned *flags;      // [team][4 slots][4*B]  tile sequence number + 1 (zeroed by the host)
+    int *err;             // set to 1 when a bounded wait ran out
+    int B, teams_per_xcd; // members per team; teams whose members share blockIdx % 8
+    int w_bytes;          // size of the packed W image
+#ifdef SKM_TRACE
+    long long *trace;
+#endif
+};
+
+#define SKM_TEAM_SPIN_LIMIT (1 << 20)
+
+template <int NCT, int NJT, int B>
+__global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
+{
+    constexpr int NF = 2 * NJT, NFW = NF * 32, PRE = 8, RING = 4;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), NWV = 4;
+    const int h = lane >> 5, c = lane & 31;
+    const TileGeom g = a.g;
+    const int tile_floats = 32 * g.XS;
+    constexpr int NC = 4 * B;
+
+    // members of a team share blockIdx % 8 (blocks are dealt round-robin over the 8 XCDs: same L2)
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int member = kk % B, team = xcd * a.teams_per_xcd + kk / B, n_teams = 8 * a.teams_per_xcd;
+    const int me = member * 4 + wave;   // this wave's contribution index = its 128-component block
+
+    float *xs = smem;                                            // [RING][32][XS]
+    float *ls = xs + RING * tile_floats + wave * 32;             // wave-private row of 32
+    f32x4 *stash = reinterpret_cast<f32x4 *>(xs + RING * tile_floats + NWV * 32) + wave * (NCT * 4 * 64) + lane;
+
+    {
+        const int padw = g.XS - g.D;
+        for (int i = tid; i < RING * 32 * padw; i += nthr) {
+            const int row = i / padw, col = g.D + (i - row * padw);
+            xs[row * g.XS + col] = (col == g.D) ? 1.0f : 0.0f;
+        }
+    }
+    float kcv[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) kcv[ct] = a.kc[(me * NCT + ct) * 32 + c];
+    WStream Wg4;
+    Wg4.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp), 0, a.w_bytes, 0x00027000);
+    Wg4.voff = lane * 16;
+    Wg4.sbase = me * (NCT * g.NG * 1024);
+
+    f32x16 acc[NCT][NF];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int jf = 0; jf < NF; ++jf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
+
+    const long tiles = (a.T + 31) >> 5;
+    const long ta = tiles * team / n_teams, tb = tiles * (team + 1) / n_teams;
+    double *slab_lane = a.slabs + ((long)(team * B + member) * NWV + wave) * (long)(NCT * 32 * NFW) + (4 * h) * NFW + c;
+    double llk_lane = 0.0;
+    float *xch = a.xch + (long)team * (4 * NC * 64);
+    unsigned *flags = a.flags + (long)team * (4 * NC);
+    bool dead = false;
+    SKM_TRACE_DECL;
+
+    TileStager<PRE> stg;
+    stg.init(g, tid, nthr);
+    if (ta < tb) {
+        const long t0 = ta << 5;
+        stg.load(a.X, t0, (int)((a.T - t0) < 32 ? (a.T - t0) : 32), g.D);
+        stg.store(xs);
+        if (ta + 1 < tb) stg.load(a.X, t0 + 32, (int)((a.T - t0 - 32) < 32 ? (a.T - t0 - 32) : 32), g.D);
+    }
+    WSet<NCT> wa;
+    wset_load<NCT>(wa, Wg4, g.NG, g.NP, 0);
+    __syncthreads();
+
+    // The partial rows of a tile are fetched in two steps that are issued early and consumed late:
+    // poll_issue (one agent-scope load of the team's flags, behind the logits GEMM), collect (the 8-byte
+    // (max, sum) pairs, requested before the LDS stash swap and the barrier), finish_tile (uses them).
+    constexpr int KH = NC / 2;   // contributions per lane half
+    unsigned long long part[KH];
+    unsigned flag_seen = 0;
+    auto poll_issue = [&](long tile) __attribute__((always_inline)) {
+        const int slot = (int)((tile - ta) & 3);
+        flag_seen = 0;
+        if (lane < NC) flag_seen = __hip_atomic_load(flags + slot * NC + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto collect = [&](long tile) __attribute__((always_inline)) {
+        const int slot = (int)((tile - ta) & 3);
+        const unsigned expect = (unsigned)(tile - ta) + 1u;
+        const unsigned *fl = flags + slot * NC;
+        int spins = 0;
+        unsigned v = (lane < NC) ? flag_seen : expect;
+        while (!dead && __builtin_amdgcn_ballot_w64(v != expect) != 0) {
+            if (++spins > SKM_TEAM_SPIN_LIMIT) {
+                dead = true;
+                if (lane == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_sleep(8);
+            if (lane < NC) v = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("" ::: "memory");
+#ifdef SKM_TRACE
+        if (trace_now) a.trace[wave * 16 + 12] = 1000000 + spins;
+#endif
+        // lane (c, h) takes the contributions k = h, h+2, ... of frame c: one base address, constant strides
+        const unsigned long long *row =
+            reinterpret_cast<const unsigned long long *>(xch) + (long)slot * NC * 32 + h * 32 + c;
+#pragma unroll
+        for (int i = 0; i < KH; ++i) part[i] = __hip_atomic_load(row + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // gamma and statistics of tile `tile` (its e values are in lg, its partial rows in part[])
+    auto finish_tile = [&](f32x16 (&lg)[NCT], long tile) __attribute__((always_inline)) {
+        const long t0 = tile << 5;
+        const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
+        float mx = -3.0e38f, sum = 0.f, m_me = 0.f;
+        {
+#pragma unroll
+            for (int i = 0; i < KH; ++i) {
+                const float pm = __builtin_bit_cast(float, (unsigned)(part[i] & 0xffffffffull));
+                mx = __builtin_fmaxf(mx, pm);
+                if (2 * i == (me & ~1)) m_me = pm;   // the half h == (me & 1) holds this wave's own row
+            }
+#pragma unroll
+            for (int i = 0; i < KH; ++i) {           // independent exponentials, no serial rescaling chain
+                const float pm = __builtin_bit_cast(float, (unsigned)(part[i] & 0xffffffffull));
+                const float ps = __builtin_bit_cast(float, (unsigned)(part[i] >> 32));
+                sum += ps * __builtin_amdgcn_exp2f(pm - mx);
+            }
+            const float omx = __shfl_xor(mx, 32), osum = __shfl_xor(sum, 32), ome = __shfl_xor(m_me, 32);
+            const float nm = __builtin_fmaxf(mx, omx);
+            sum = sum * __builtin_amdgcn_exp2f(mx - nm) + osum * __builtin_amdgcn_exp2f(omx - nm);
+            mx = nm;
+            if ((me & 1) != h) m_me = ome;
+        }
+        {
+            const bool valid = c < nvalid;
+            const float f = __builtin_amdgcn_exp2f(m_me - mx) * __builtin_amdgcn_rcpf(sum);
+            if (h == 0) ls[c] = valid ? f : 0.f;
+            if (me == 0 && h == 0 && valid) llk_lane += (double)(mx + __builtin_amdgcn_logf(sum));
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 f4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                lg[ct][4 * q4 + 0] *= f4[0];
+                lg[ct][4 * q4 + 1] *= f4[1];
+                lg[ct][4 * q4 + 2] *= f4[2];
+                lg[ct][4 * q4 + 3] *= f4[3];
+            }
+        }
+        // frames of tile+3 are requested here (the statistics GEMM has no other vector-memory wait)
+        if (tile + 3 < tb) {
+            const long t3 = (tile + 3) << 5;
+            stg.load(a.X, t3, (int)((a.T - t3) < 32 ? (a.T - t3) : 32), g.D);
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
+        const float *xt = xs + (int)((tile - ta) & (RING - 1)) * tile_floats;
+        SKM_STAMP(5);
+        gemm_stats_agpr<NJT, NCT>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
+        wave_lds_fence();
+    };
+
+    for (long base = ta; base < tb; base += SKM_FLUSH_TILES) {
+        const long end = (base + SKM_FLUSH_TILES < tb) ? base + SKM_FLUSH_TILES : tb;
+#pragma unroll 1
+        for (long tile = base; tile < end; ++tile) {
+            const int cur = (int)((tile - ta) & (RING - 1)), nxt = (cur + 1) & (RING - 1);
+            const int slot = (int)((tile - ta) & 3);
+            const float *xt = xs + cur * tile_floats;
+            SKM_TRACE_TILE;
+            SKM_STAMP(0);
+
+            f32x16 lg[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                float k = kcv[ct];
+                asm volatile("" : "+v"(k));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lg[ct][r] = k;
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
+            gemm_logits_fat<NCT>(lg, wa, xt + c * g.XS, h, Wg4, g);
+            SKM_STAMP(1);
+            if (tile > ta) poll_issue(tile - 1);
+
+            // exact per-frame maximum over this wave's 128 components, e = 2^(l - max), per-frame sum of e
+            float m[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                m[r] = lg[0][r];
+#pragma unroll
+                for (int ct = 1; ct < NCT; ++ct) m[r] = __builtin_fmaxf(m[r], lg[ct][r]);
+            }
+            lane_reduce16(m, c, OpMax());
+            const int frame = acc_row((c >> 1) & 15, h);
+            if ((c & 1) == 0) ls[frame] = m[0];
+            wave_lds_fence();
+            float sm[16];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float acc1 = 0.f;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        const float e = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + i] - m4[i]);
+                        lg[ct][4 * q4 + i] = e;
+                        acc1 += e;
+                    }
+                    sm[4 * q4 + i] = acc1;
+                }
+            }
+            lane_reduce16(sm, c, OpAdd());
+            // publish this wave's row of partials, then its flag
+            if ((c & 1) == 0) {
+                unsigned long long *row = reinterpret_cast<unsigned long long *>(xch) + ((long)slot * NC + me) * 32 + frame;
+                const unsigned long long pr = (unsigned long long)__builtin_bit_cast(unsigned, m[0]) |
+                                              ((unsigned long long)__builtin_bit_cast(unsigned, sm[0]) << 32);
+                __hip_atomic_store(row, pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wave_lds_fence();   // ls is rewritten by finish_tile
+            SKM_STAMP(2);
+
+            // e(tile) waits in the wave's LDS stash while e(tile-1) comes back out
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                    if (tile > ta) o = stash[(ct * 4 + q) * 64];
+                    const f32x4 n = {lg[ct][4 * q], lg[ct][4 * q + 1], lg[ct][4 * q + 2], lg[ct][4 * q + 3]};
+                    stash[(ct * 4 + q) * 64] = n;
+                    lg[ct][4 * q] = o[0];
+                    lg[ct][4 * q + 1] = o[1];
+                    lg[ct][4 * q + 2] = o[2];
+                    lg[ct][4 * q + 3] = o[3];
+                }
+            if (tile + 1 < tb) stg.store(xs + nxt * tile_floats);
+            // tile+2 must be in registers before finish_tile requests tile+3 ... on the first tile only
+            // tile+1 has been requested so far
+            if (tile == ta && tile + 2 < tb) {
+                const long t2 = (tile + 2) << 5;
+                stg.load(a.X, t2, (int)((a.T - t2) < 32 ? (a.T - t2) : 32), g.D);
+            }
+            // flag of this tile's row: the sc1 stores issued above are complete at the coherence point once
+            // acknowledged, so draining them (by now they are old) is all the release this hand-off needs; an
+            // agent-scope release fence would write back the whole L2 (buffer_wbl2) every tile
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store(flags + slot * NC + me, (unsigned)(tile - ta) + 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            SKM_STAMP(3);
+            if (tile > ta) collect(tile - 1);   // the rows of tile-1 travel while the workgroup meets at the barrier
+            __syncthreads();
+            SKM_STAMP(4);
+            if (tile > ta) finish_tile(lg, tile - 1);
+            SKM_STAMP(6);
+        }
+        // the accumulators are touched by nothing but the asm MFMAs inside the tile loop: they stay in AGPRs
+        if (end == tb && ta < tb) {
+            f32x16 lg[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 o = stash[(ct * 4 + q) * 64];
+                    lg[ct][4 * q] = o[0];
+                    lg[ct][4 * q + 1] = o[1];
+                    lg[ct][4 * q + 2] = o[2];
+                    lg[ct][4 * q + 3] = o[3];
+                }
+            poll_issue(tb - 1);
+            collect(tb - 1);
+            finish_tile(lg, tb - 1);
+        }
+        flush_slab_agpr<NCT, NF>(acc, slab_lane);
+    }
+    if (me == 0) {
+#pragma unroll
+        for (int msk = 1; msk < 32; msk <<= 1) llk_lane += __shfl_xor(llk_lane, msk);
+        if (lane == 0) a.llk_part[team] = llk_lane * 0.6931471805599453094;
+    }
+}
+
 // Sum the per-wave f64 slabs in a fixed order into out = [N | F | S | llk].
 __global__ __launch_bounds__(256) void k_reduce_slabs(const double *__restrict__ slabs, int n_cb, int n_fs, int NW,
                                                       int NCT, int NJT, int NF, int C, int D,
                                                       double *__restrict__ out, int accumulate,
-                                                      const double *__restrict__ llk_part, int n_llk)
+                                                      const double *__restrict__ llk_part, int n_llk,
+                                                      const int *__restrict__ err = nullptr)
 {
     const int NFW = NF * 32;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0) {
         double l = 0.0;
         for (int i = 0; i < n_llk; ++i) l += llk_part[i];
+        if (err && *err) l = __builtin_nan("");   // a team hand-off timed out: the statistics are not valid
         double *p = out + C + 2L * C * D;
         *p = accumulate ? (*p + l) : l;
     }
@@ -1695,6 +2054,9 @@ struct Plan {
     // single-sweep kernel (7..16 component tiles, D <= 63)
     int fused, fused_nwv, fused_blocks, fused_fat, fat_blocks;
     size_t fused_lds;
+    // team kernel (C > 512 in multiples of 512): B workgroups per team, teams of one XCD share blockIdx % 8
+    int team, team_B, team_per_xcd, team_wgs;
+    size_t team_lds, off_xch, off_flags, off_err;
     // workspace offsets (bytes)
     size_t off_pm, off_ps, off_lse, off_llk, off_slabs, total;
 };
@@ -1766,6 +2128,18 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
     }
     p->fused_lds = ((size_t)3 * 32 * g.XS + (size_t)4 * p->fused_nwv * 32 + (size_t)p->fused_nwv * 32 +
                     (size_t)p->fused_nwv * 2 * 16 * 64) * sizeof(float);
+    // team kernel: EM statistics, C a multiple of 512 above 512, 16-byte rows with D <= 64, and a CU count
+    // that splits into teams of B workgroups per XCD (blocks are dealt round-robin over 8 XCDs)
+    {
+        const int B = g.CTpad / 16;
+        const char *e = getenv("SKM_TEAM");
+        p->team_B = B;
+        p->team_per_xcd = (B > 0) ? (wgs / 8) / B : 0;
+        p->team_wgs = 8 * p->team_per_xcd * B;
+        p->team = (with_s && g.CT == g.CTpad && g.CTpad % 16 == 0 && (B == 2 || B == 4 || B == 8) && p->team_per_xcd >= 1 &&
+                   D % 4 == 0 && D <= 64 && g.NJT <= 2 && (e ? atoi(e) != 0 : 1)) ? 1 : 0;
+        p->team_lds = ((size_t)4 * 32 * g.XS + 4 * 32 + (size_t)4 * 4 * 4 * 64 * 4) * sizeof(float);
+    }
     size_t off = 0;
     p->off_pm = off;
     off += skm_align_up((size_t)p->n_cb1 * (size_t)T * sizeof(float), 256);
@@ -1788,8 +2162,16 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         const size_t slfat = (size_t)p->fat_blocks * (g.CTpad / 4) * 128 * nf * 32 * sizeof(double);
         if (p->fused_fat && slfat > slf) slf = slfat;
         if (p->fused && slf > sl) sl = slf;
+        const size_t slteam = (size_t)p->team_wgs * 4 * 128 * nf * 32 * sizeof(double);
+        if (p->team && slteam > sl) sl = slteam;
         off += skm_align_up(sl, 256);
     }
+    p->off_flags = off;     // flags and err are cleared by one memset: keep them adjacent
+    off += skm_align_up((size_t)(p->team ? 8 * p->team_per_xcd * 4 * 4 * p->team_B : 0) * sizeof(unsigned), 256);
+    p->off_err = off;
+    off += 256;
+    p->off_xch = off;
+    off += skm_align_up((size_t)(p->team ? 8 * p->team_per_xcd * 4 * 4 * p->team_B * 64 : 0) * sizeof(float), 256);
     p->total = off;
     return SKM_OK;
 }
@@ -1967,6 +2349,61 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
                            1, fat ? 4 : 2, p.g.NJT, nf, C, D, out, accumulate, f.llk_part, p.n_llk);
         SKM_HIP(hipGetLastError());
         return SKM_OK;
+    }
+    if (p.team) {
+        TeamArgs t;
+        t.X = X;
+        t.T = T;
+        t.g = p.tg;
+        t.wp = wp;
+        t.kc = kc;
+        t.slabs = reinterpret_cast<double *>(ws + p.off_slabs);
+        t.llk_part = reinterpret_cast<double *>(ws + p.off_llk);
+        t.xch = reinterpret_cast<float *>(ws + p.off_xch);
+        t.flags = reinterpret_cast<unsigned *>(ws + p.off_flags);
+        t.err = reinterpret_cast<int *>(ws + p.off_err);
+        t.B = p.team_B;
+        t.teams_per_xcd = p.team_per_xcd;
+        t.w_bytes = p.g.CTpad * p.g.NCH * 1024;
+#ifdef SKM_TRACE
+        t.trace = g_trace;
+#endif
+        const int nf = 2 * p.g.NJT;
+        SKM_HIP(hipMemsetAsync(t.slabs, 0, (size_t)p.team_wgs * 4 * 128 * nf * 32 * sizeof(double), st));
+        SKM_HIP(hipMemsetAsync(t.llk_part, 0, p.n_llk * sizeof(double), st));
+        SKM_HIP(hipMemsetAsync(t.flags, 0, p.off_xch - p.off_flags, st));
+        void *kargs[] = {&t};
+        hipError_t le;
+        {
+            SkmProfScope ps(ctx, "k_estep_team", st);
+#define SKM_TEAM_LAUNCH(NJT_, B_)                                                                                  \
+    do {                                                                                                          \
+        if ((rc = set_lds(k_estep_team<4, NJT_, B_>, p.team_lds))) return rc;                                     \
+        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_estep_team<4, NJT_, B_>),                \
+                                        dim3(p.team_wgs), dim3(256), kargs, (unsigned)p.team_lds, st);            \
+    } while (0)
+            le = hipErrorInvalidValue;
+            if (p.g.NJT == 1) {
+                if (p.team_B == 2) SKM_TEAM_LAUNCH(1, 2);
+                else if (p.team_B == 4) SKM_TEAM_LAUNCH(1, 4);
+                else if (p.team_B == 8) SKM_TEAM_LAUNCH(1, 8);
+            } else {
+                if (p.team_B == 2) SKM_TEAM_LAUNCH(2, 2);
+                else if (p.team_B == 4) SKM_TEAM_LAUNCH(2, 4);
+                else if (p.team_B == 8) SKM_TEAM_LAUNCH(2, 8);
+            }
+#undef SKM_TEAM_LAUNCH
+        }
+        if (le == hipSuccess) {
+            const long n_out = (long)C * nf * 32;
+            SkmProfScope ps(ctx, "k_reduce_slabs", st);
+            hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, t.slabs,
+                               4 * p.team_B, 8 * p.team_per_xcd, 1, 4, p.g.NJT, nf, C, D, out, accumulate, t.llk_part,
+                               p.n_llk, t.err);
+            SKM_HIP(hipGetLastError());
+            return SKM_OK;
+        }
+        (void)hipGetLastError();   // the teams cannot all be resident on this device: two sweeps instead
     }
     if ((rc = launch_lse(ctx, p, X, T, wp, kc, ws, nullptr, st))) return rc;
     StatsArgs a;

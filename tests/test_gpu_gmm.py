@@ -73,7 +73,9 @@ def test_estep_vs_reference_golden(eng, tag):
 
 
 @pytest.mark.parametrize("C,D,T", [(1, 60, 1000), (2, 60, 33), (33, 60, 4097), (512, 60, 20000), (96, 20, 5000),
-                                   (64, 132, 3000), (130, 7, 2049), (256, 39, 7001), (2048, 60, 6000)])
+                                   (64, 132, 3000), (130, 7, 2049), (256, 39, 7001), (2048, 60, 6000),
+                                   # team kernel (C = 1024 / 2048 / 4096): ragged last tile, fewer tiles than teams, one frame
+                                   (1024, 60, 9999), (2048, 20, 12345), (2048, 60, 95), (1024, 64, 1), (4096, 60, 4100)])
 def test_estep_vs_oracle_shapes(eng, C, D, T):
     gmm = orc.random_gmm(C, D, seed=C + D)
     cep = orc.synth_frames(T, dim=D, clusters=16, seed=T)
@@ -250,3 +252,29 @@ def test_log_posterior_matrix_mu_override(sk, C, D, T):
     one = m.compute_log_posterior_probabilities(cep[0])
     assert one.shape == (1, C)
     assert np.abs(one - orc.log_posterior(gmm, cep[:1])).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_team_kernel_matches_two_sweeps_and_accumulates(eng):
+    """C = 2048 takes the single-sweep team kernel (cross-workgroup logsumexp hand-off); SKM_TEAM=0 is the
+    two-sweep path.  Same statistics to float32 rounding, bit-identical on repeat, and `accumulate` adds."""
+    import os
+    C, D, T = 2048, 60, 70001
+    gmm = orc.random_gmm(C, D, seed=3)
+    cep = orc.synth_frames(T, D, seed=4)
+    X = eng.upload_frames(cep)
+    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    a = eng.to_host(eng.estep(X, packed))
+    b = eng.to_host(eng.estep(X, packed))
+    np.testing.assert_array_equal(a, b)
+    assert np.isfinite(a).all()
+    os.environ["SKM_TEAM"] = "0"
+    try:
+        two = eng.to_host(eng.estep(X, packed))
+    finally:
+        del os.environ["SKM_TEAM"]
+    N1, F1, S1, l1 = unpack(a, C, D)
+    N2, F2, S2, l2 = unpack(two, C, D)
+    assert rel(N1, N2) < 2e-5 and rel(F1, F2) < 2e-5 and rel(S1, S2) < 2e-5 and abs(l1 - l2) < 1e-5 * abs(l2)
+    out = eng.estep(X, packed)
+    out = eng.estep(X, packed, out=out, accumulate=True)
+    np.testing.assert_allclose(eng.to_host(out), 2.0 * a, rtol=1e-12)

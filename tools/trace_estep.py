@@ -18,9 +18,10 @@ eng.lib.skm_trace_buffer(ctypes.c_void_p(buf.data_ptr()))
 eng.estep(X, packed)
 torch.cuda.synchronize()
 t = buf.cpu().numpy().reshape(8, 16)
-base = t[t > 0].min()
-names = ["start", "logits", "lse_part", "staged", "bar/stash", "exp", "stats", "fence", "bar(late)", "lg_q2", "lg_q4", "lg_loopend"]
+tt = t.copy(); tt[:, 12] = 0
+base = tt[tt > 0].min()
+names = ["start", "logits", "lse_part", "staged", "bar/stash", "exp", "stats", "fence", "bar(late)", "lg_q2", "lg_q4", "lg_loopend", "spins"]
 print("stagger", os.environ.get("SKM_STAGGER", "1"), " stamps relative to the earliest, cycles")
 print("wave " + " ".join("%10s" % n for n in names))
 for w in range(8):
-    print("%4d " % w + " ".join("%10d" % (t[w, k] - base if t[w, k] else -1) for k in range(len(names))))
+    print("%4d " % w + " ".join("%10d" % ((t[w, k] - base if k != 12 else t[w, k] - 1000000) if t[w, k] else -1) for k in range(len(names))))
