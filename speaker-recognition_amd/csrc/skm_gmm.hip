@@ -1246,8 +1246,8 @@ __device__ __forceinline__ void gemm_logits_fat(f32x16 (&lg)[NCT], WSet<NCT> &wa
     }
 }
 
-template <int NJT, int NCT>
-__device__ __forceinline__ void gemm_stats_agpr(f32x16 (&acc)[NCT][2 * NJT], const f32x16 (&lg)[NCT],
+template <int NJT, int NCT, bool WITH_S = true>
+__device__ __forceinline__ void gemm_stats_agpr(f32x16 (&acc)[NCT][NJT * (WITH_S ? 2 : 1)], const f32x16 (&lg)[NCT],
                                                 const float *xcol, int XS)
 {
     float bn[NJT];
@@ -1270,15 +1270,17 @@ __device__ __forceinline__ void gemm_stats_agpr(f32x16 (&acc)[NCT][2 * NJT], con
         for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) mfma_agpr(acc[ct][jt], lg[ct][r], b[jt]);
+        if (WITH_S) {
 #pragma unroll
-        for (int jt = 0; jt < NJT; ++jt)
+            for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                if (ct == 0)
-                    mfma_agpr_after_valu(acc[ct][NJT + jt], lg[ct][r], b2[jt]);
-                else
-                    mfma_agpr(acc[ct][NJT + jt], lg[ct][r], b2[jt]);
-            }
+                for (int ct = 0; ct < NCT; ++ct) {
+                    if (ct == 0)
+                        mfma_agpr_after_valu(acc[ct][NJT * (WITH_S ? 1 : 0) + jt], lg[ct][r], b2[jt]);
+                    else
+                        mfma_agpr(acc[ct][NJT * (WITH_S ? 1 : 0) + jt], lg[ct][r], b2[jt]);
+                }
+        }
     }
 }
 
@@ -1562,6 +1564,33 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
 // workgroups co-resident or the launch fails and the host falls back to two sweeps); every poll loop is
 // bounded and raises *err instead of spinning forever.
 // ------------------------------------------------------------------------------------------------
+// Baum-Welch flush of AGPR accumulators (one store per session, see flush_session); C is a multiple of
+// NCT * 32 for every caller, so every accumulator row is a live component.
+template <int NCT, int NF>
+__device__ __forceinline__ void flush_session_agpr(f32x16 (&acc)[NCT][NF], double *s0, double *s1, int cb, int D,
+                                                   int lane)
+{
+    const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int jf = 0; jf < NF; ++jf) {
+            agpr_settle(acc[ct][jf]);
+            const f32x16 v = acc[ct][jf];
+            const int col = jf * 32 + c;
+            const int comp0 = (cb * NCT + ct) * 32 + 4 * h;
+            double *p = (col < D) ? (s1 + (long)comp0 * D + col) : (s0 + comp0);
+            const long stride = (col < D) ? D : 1;
+            if (col <= D) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[acc_row(r, 0) * stride] = (double)v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
 template <int PRE>
 struct TileStager {
     static constexpr int NST = PRE / 4;
@@ -1614,6 +1643,10 @@ struct TeamArgs {
     unsigned *flags;      // [team][4 slots][4*B]  tile sequence number + 1 (zeroed by the host)
     int *err;             // set to 1 when a bounded wait ran out
     int B, teams_per_xcd; // members per team; teams whose members share blockIdx % 8
+    // Baum-Welch mode: sessions [seg_off[s], seg_off[s+1]) -> stat0[S][C], stat1[S][C*D]
+    const int64_t *seg_off;
+    int S, C;
+    double *stat0, *stat1;
     int w_bytes;          // size of the packed W image
 #ifdef SKM_TRACE
     long long *trace;
@@ -1622,6 +1655,9 @@ struct TeamArgs {
 
 #define SKM_TEAM_SPIN_LIMIT (1 << 20)
 
+// EM statistics: the team's tiles in one run, slabs folded every SKM_FLUSH_TILES tiles.  (k_seg_team below is
+// the same pipeline cut into segments with a flush per segment -- one session each -- for Baum-Welch; its
+// EM instantiation allocates registers worse than this dedicated kernel, 50 vs 36 ms at C=2048, so both stay.)
 template <int NCT, int NJT, int B>
 __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
 {
@@ -1901,6 +1937,313 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
     }
 }
 
+template <int NCT, int NJT, int B, bool BW>
+__global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
+{
+    constexpr int NF = BW ? NJT : 2 * NJT, NFW = NF * 32, PRE = 8, RING = 4, NC = 4 * B;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), NWV = 4;
+    const int h = lane >> 5, c = lane & 31;
+    const TileGeom g = a.g;
+    const int tile_floats = 32 * g.XS;
+
+    // members of a team share blockIdx % 8 (blocks are dealt round-robin over the 8 XCDs: same L2)
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int member = kk % B, team = xcd * a.teams_per_xcd + kk / B, n_teams = 8 * a.teams_per_xcd;
+    const int me = member * 4 + wave;   // this wave's contribution index = its 128-component block
+
+    float *xs = smem;                                            // [RING][32][XS]
+    float *ls = xs + RING * tile_floats + wave * 32;             // wave-private row of 32
+    f32x4 *stash = reinterpret_cast<f32x4 *>(xs + RING * tile_floats + NWV * 32) + wave * (NCT * 4 * 64) + lane;
+
+    {
+        const int padw = g.XS - g.D;
+        for (int i = tid; i < RING * 32 * padw; i += nthr) {
+            const int row = i / padw, col = g.D + (i - row * padw);
+            xs[row * g.XS + col] = (col == g.D) ? 1.0f : 0.0f;
+        }
+    }
+    float kcv[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) kcv[ct] = a.kc[(me * NCT + ct) * 32 + c];
+    WStream Wg4;
+    Wg4.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp), 0, a.w_bytes, 0x00027000);
+    Wg4.voff = lane * 16;
+    Wg4.sbase = me * (NCT * g.NG * 1024);
+
+    f32x16 acc[NCT][NF];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int jf = 0; jf < NF; ++jf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
+
+    double llk_lane = 0.0;
+    float *xch = a.xch + (long)team * (4 * NC * 64);
+    unsigned *flags = a.flags + (long)team * (4 * NC);
+    bool dead = false;
+    unsigned n = 0;   // tiles this team has started: slot = n & 3, flag value = n + 1 (same on every member)
+    SKM_TRACE_DECL;
+
+    TileStager<PRE> stg;
+    stg.init(g, tid, nthr);
+    WSet<NCT> wa;
+    wset_load<NCT>(wa, Wg4, g.NG, g.NP, 0);
+
+    // The partial rows of a tile are fetched in two steps that are issued early and consumed late:
+    // poll_issue (one agent-scope load of the team's flags, behind the logits GEMM), collect (the 8-byte
+    // (max, sum) pairs, requested right before the barrier), finish_tile (uses them).
+    constexpr int KH = NC / 2;   // contributions per lane half
+    unsigned long long part[KH];
+    unsigned flag_seen = 0;
+    auto poll_issue = [&](unsigned ni) __attribute__((always_inline)) {
+        flag_seen = 0;
+        if (lane < NC)
+            flag_seen = __hip_atomic_load(flags + (ni & 3) * NC + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto collect = [&](unsigned ni) __attribute__((always_inline)) {
+        const int slot = (int)(ni & 3);
+        const unsigned expect = ni + 1u;
+        const unsigned *fl = flags + slot * NC;
+        int spins = 0;
+        unsigned v = (lane < NC) ? flag_seen : expect;
+        while (!dead && __builtin_amdgcn_ballot_w64(v != expect) != 0) {
+            if (++spins > SKM_TEAM_SPIN_LIMIT) {
+                dead = true;
+                if (lane == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_sleep(8);
+            if (lane < NC) v = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("" ::: "memory");
+        // lane (c, h) takes the contributions k = h, h+2, ... of frame c: one base address, constant strides
+        const unsigned long long *row =
+            reinterpret_cast<const unsigned long long *>(xch) + (long)slot * NC * 32 + h * 32 + c;
+#pragma unroll
+        for (int i = 0; i < KH; ++i) part[i] = __hip_atomic_load(row + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // gamma and statistics of tile ni (its e values are in lg, its partial rows in part[]); t_pf >= 0 names
+    // the frames to request for a later tile (the statistics GEMM has no other vector-memory wait)
+    auto finish_tile = [&](f32x16 (&lg)[NCT], unsigned ni, int nvalid, long t_pf, int nv_pf) __attribute__((always_inline)) {
+        float mx = -3.0e38f, sum = 0.f, m_me = 0.f;
+        {
+#pragma unroll
+            for (int i = 0; i < KH; ++i) {
+                const float pm = __builtin_bit_cast(float, (unsigned)(part[i] & 0xffffffffull));
+                mx = __builtin_fmaxf(mx, pm);
+                if (2 * i == (me & ~1)) m_me = pm;   // the half h == (me & 1) holds this wave's own row
+            }
+#pragma unroll
+            for (int i = 0; i < KH; ++i) {           // independent exponentials, no serial rescaling chain
+                const float pm = __builtin_bit_cast(float, (unsigned)(part[i] & 0xffffffffull));
+                const float ps = __builtin_bit_cast(float, (unsigned)(part[i] >> 32));
+                sum += ps * __builtin_amdgcn_exp2f(pm - mx);
+            }
+            const float omx = __shfl_xor(mx, 32), osum = __shfl_xor(sum, 32), ome = __shfl_xor(m_me, 32);
+            const float nm = __builtin_fmaxf(mx, omx);
+            sum = sum * __builtin_amdgcn_exp2f(mx - nm) + osum * __builtin_amdgcn_exp2f(omx - nm);
+            mx = nm;
+            if ((me & 1) != h) m_me = ome;
+        }
+        {
+            const bool valid = c < nvalid;
+            const float f = __builtin_amdgcn_exp2f(m_me - mx) * __builtin_amdgcn_rcpf(sum);
+            if (h == 0) ls[c] = valid ? f : 0.f;
+            if (!BW && me == 0 && h == 0 && valid) llk_lane += (double)(mx + __builtin_amdgcn_logf(sum));
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 f4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                lg[ct][4 * q4 + 0] *= f4[0];
+                lg[ct][4 * q4 + 1] *= f4[1];
+                lg[ct][4 * q4 + 2] *= f4[2];
+                lg[ct][4 * q4 + 3] *= f4[3];
+            }
+        }
+        if (t_pf >= 0) stg.load(a.X, t_pf, nv_pf, g.D);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
+        const float *xt = xs + (int)(ni & (RING - 1)) * tile_floats;
+        SKM_STAMP(5);
+        gemm_stats_agpr<NJT, NCT, !BW>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
+        wave_lds_fence();
+    };
+
+    // One segment = frames [b, e) whose statistics go to one flush (EM: 256 tiles, BW: one session).  The
+    // pipeline is filled and drained per segment; the accumulators are touched by nothing but the asm MFMAs
+    // inside the tile loop, so they stay in AGPRs between the flushes.
+    auto run_segment = [&](long b, long e) __attribute__((always_inline)) {
+        const int ntile = (int)((e - b + 31) >> 5);
+        if (ntile == 0) return;
+        auto nv = [&](int i) __attribute__((always_inline)) {
+            const long left = e - (b + 32L * i);
+            return (int)(left < 32 ? left : 32);
+        };
+        stg.load(a.X, b, nv(0), g.D);
+        stg.store(xs + (int)(n & (RING - 1)) * tile_floats);
+        if (ntile > 1) stg.load(a.X, b + 32, nv(1), g.D);
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < ntile; ++i) {
+            const unsigned ni = n + (unsigned)i;
+            const int cur = (int)(ni & (RING - 1)), nxt = (cur + 1) & (RING - 1), slot = (int)(ni & 3);
+            const float *xt = xs + cur * tile_floats;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int jf = 0; jf < NF; ++jf) asm volatile("" : "+a"(acc[ct][jf]));
+#ifdef SKM_TRACE
+            trace_now = a.trace && blockIdx.x == 8 && lane == 0 && ni == 40;
+#endif
+            SKM_STAMP(0);
+
+            f32x16 lg[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                float k = kcv[ct];
+                asm volatile("" : "+v"(k));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lg[ct][r] = k;
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
+            gemm_logits_fat<NCT>(lg, wa, xt + c * g.XS, h, Wg4, g);
+            SKM_STAMP(1);
+            if (i > 0) poll_issue(ni - 1);
+
+            // exact per-frame maximum over this wave's 128 components, e = 2^(l - max), per-frame sum of e
+            float m[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                m[r] = lg[0][r];
+#pragma unroll
+                for (int ct = 1; ct < NCT; ++ct) m[r] = __builtin_fmaxf(m[r], lg[ct][r]);
+            }
+            lane_reduce16(m, c, OpMax());
+            const int frame = acc_row((c >> 1) & 15, h);
+            if ((c & 1) == 0) ls[frame] = m[0];
+            wave_lds_fence();
+            float sm[16];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float acc1 = 0.f;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        const float ev = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + j] - m4[j]);
+                        lg[ct][4 * q4 + j] = ev;
+                        acc1 += ev;
+                    }
+                    sm[4 * q4 + j] = acc1;
+                }
+            }
+            lane_reduce16(sm, c, OpAdd());
+            // publish this wave's row of partials (the flag follows below, once the stores have drained)
+            if ((c & 1) == 0) {
+                unsigned long long *row = reinterpret_cast<unsigned long long *>(xch) + ((long)slot * NC + me) * 32 + frame;
+                const unsigned long long pr = (unsigned long long)__builtin_bit_cast(unsigned, m[0]) |
+                                              ((unsigned long long)__builtin_bit_cast(unsigned, sm[0]) << 32);
+                __hip_atomic_store(row, pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wave_lds_fence();   // ls is rewritten by finish_tile
+            SKM_STAMP(2);
+
+            // e(i) waits in the wave's LDS stash while e(i-1) comes back out
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                    if (i > 0) o = stash[(ct * 4 + q) * 64];
+                    const f32x4 nw = {lg[ct][4 * q], lg[ct][4 * q + 1], lg[ct][4 * q + 2], lg[ct][4 * q + 3]};
+                    stash[(ct * 4 + q) * 64] = nw;
+                    lg[ct][4 * q] = o[0];
+                    lg[ct][4 * q + 1] = o[1];
+                    lg[ct][4 * q + 2] = o[2];
+                    lg[ct][4 * q + 3] = o[3];
+                }
+            if (i + 1 < ntile) stg.store(xs + nxt * tile_floats);
+            // from here on finish_tile(i-1) requests tile i+2; the first iteration has no finish_tile
+            if (i == 0 && ntile > 2) stg.load(a.X, b + 64, nv(2), g.D);
+            // flag of this tile's row: the sc1 stores issued above are complete at the coherence point once
+            // acknowledged, so draining them (by now they are old) is all the release this hand-off needs; an
+            // agent-scope release fence would write back the whole L2 (buffer_wbl2) every tile
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store(flags + slot * NC + me, ni + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            SKM_STAMP(3);
+            if (i > 0) collect(ni - 1);   // the rows of tile i-1 travel while the workgroup meets at the barrier
+            __syncthreads();
+            SKM_STAMP(4);
+            if (i > 0) finish_tile(lg, ni - 1, nv(i - 1), (i + 2 < ntile) ? b + 32L * (i + 2) : -1L, (i + 2 < ntile) ? nv(i + 2) : 0);
+            SKM_STAMP(6);
+        }
+        {   // drain: the last tile of the segment
+            f32x16 lg[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 o = stash[(ct * 4 + q) * 64];
+                    lg[ct][4 * q] = o[0];
+                    lg[ct][4 * q + 1] = o[1];
+                    lg[ct][4 * q + 2] = o[2];
+                    lg[ct][4 * q + 3] = o[3];
+                }
+            const unsigned nl = n + (unsigned)ntile - 1u;
+            poll_issue(nl);
+            collect(nl);
+            finish_tile(lg, nl, nv(ntile - 1), -1L, 0);
+        }
+        n += (unsigned)ntile;
+    };
+
+    if (!BW) {
+        const long tiles = (a.T + 31) >> 5;
+        const long fa = (tiles * team / n_teams) << 5;
+        long fb = (tiles * (team + 1) / n_teams) << 5;
+        if (fb > a.T) fb = a.T;
+        double *slab_lane =
+            a.slabs + ((long)(team * B + member) * NWV + wave) * (long)(NCT * 32 * NFW) + (4 * h) * NFW + c;
+        for (long b = fa; b < fb; b += 32L * SKM_FLUSH_TILES) {
+            const long e = (b + 32L * SKM_FLUSH_TILES < fb) ? b + 32L * SKM_FLUSH_TILES : fb;
+            run_segment(b, e);
+            flush_slab_agpr<NCT, NF>(acc, slab_lane);
+        }
+        if (me == 0) {
+#pragma unroll
+            for (int msk = 1; msk < 32; msk <<= 1) llk_lane += __shfl_xor(llk_lane, msk);
+            if (lane == 0) a.llk_part[team] = llk_lane * 0.6931471805599453094;
+        }
+    } else {
+        // sessions are cut into contiguous runs of about equal frame counts (lower bounds on seg_off)
+        const int64_t *so = a.seg_off;
+        const long total = so[a.S];
+        auto lower = [&](long target) __attribute__((always_inline)) {
+            int lo = 0, hi = a.S;   // first s in [0, S] with so[s] >= target
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (so[mid] < target) lo = mid + 1; else hi = mid;
+            }
+            return lo;
+        };
+        const int sa = (team == 0) ? 0 : lower(total * team / n_teams);
+        const int sb = (team == n_teams - 1) ? a.S : lower(total * (team + 1) / n_teams);
+#pragma unroll 1
+        for (int sidx = sa; sidx < sb; ++sidx) {
+            run_segment(so[sidx], so[sidx + 1]);
+            flush_session_agpr<NCT, NF>(acc, a.stat0 + (long)sidx * a.C, a.stat1 + (long)sidx * a.C * g.D, me, g.D, lane);
+        }
+    }
+}
+
 // Sum the per-wave f64 slabs in a fixed order into out = [N | F | S | llk].
 __global__ __launch_bounds__(256) void k_reduce_slabs(const double *__restrict__ slabs, int n_cb, int n_fs, int NW,
                                                       int NCT, int NJT, int NF, int C, int D,
@@ -2136,7 +2479,7 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         p->team_B = B;
         p->team_per_xcd = (B > 0) ? (wgs / 8) / B : 0;
         p->team_wgs = 8 * p->team_per_xcd * B;
-        p->team = (with_s && g.CT == g.CTpad && g.CTpad % 16 == 0 && (B == 2 || B == 4 || B == 8) && p->team_per_xcd >= 1 &&
+        p->team = (g.CT == g.CTpad && g.CTpad % 16 == 0 && (B == 2 || B == 4 || B == 8) && p->team_per_xcd >= 1 &&
                    D % 4 == 0 && D <= 64 && g.NJT <= 2 && (e ? atoi(e) != 0 : 1)) ? 1 : 0;
         p->team_lds = ((size_t)4 * 32 * g.XS + 4 * 32 + (size_t)4 * 4 * 4 * 64 * 4) * sizeof(float);
     }
@@ -2365,6 +2708,10 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
         t.B = p.team_B;
         t.teams_per_xcd = p.team_per_xcd;
         t.w_bytes = p.g.CTpad * p.g.NCH * 1024;
+        t.seg_off = nullptr;
+        t.S = 0;
+        t.C = C;
+        t.stat0 = t.stat1 = nullptr;
 #ifdef SKM_TRACE
         t.trace = g_trace;
 #endif
@@ -2378,8 +2725,8 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
             SkmProfScope ps(ctx, "k_estep_team", st);
 #define SKM_TEAM_LAUNCH(NJT_, B_)                                                                                  \
     do {                                                                                                          \
-        if ((rc = set_lds(k_estep_team<4, NJT_, B_>, p.team_lds))) return rc;                                     \
-        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_estep_team<4, NJT_, B_>),                \
+        if ((rc = set_lds(k_estep_team<4, NJT_, B_>, p.team_lds))) return rc;                              \
+        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_estep_team<4, NJT_, B_>),         \
                                         dim3(p.team_wgs), dim3(256), kargs, (unsigned)p.team_lds, st);            \
     } while (0)
             le = hipErrorInvalidValue;
@@ -2478,6 +2825,53 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
     char *ws = static_cast<char *>(ws_);
     const float *wp = static_cast<const float *>(packed);
     const float *kc = wp + (size_t)p.g.CTpad * p.g.NCH * 256;
+    if (p.team) {
+        TeamArgs t;
+        memset(&t, 0, sizeof(t));
+        t.X = X;
+        t.T = T;
+        t.g = p.tg;
+        t.wp = wp;
+        t.kc = kc;
+        t.xch = reinterpret_cast<float *>(ws + p.off_xch);
+        t.flags = reinterpret_cast<unsigned *>(ws + p.off_flags);
+        t.err = reinterpret_cast<int *>(ws + p.off_err);
+        t.B = p.team_B;
+        t.teams_per_xcd = p.team_per_xcd;
+        t.w_bytes = p.g.CTpad * p.g.NCH * 1024;
+        t.seg_off = seg_off;
+        t.S = S;
+        t.C = C;
+        t.stat0 = stat0;
+        t.stat1 = stat1;
+#ifdef SKM_TRACE
+        t.trace = g_trace;
+#endif
+        SKM_HIP(hipMemsetAsync(t.flags, 0, p.off_xch - p.off_flags, st));
+        void *kargs[] = {&t};
+        hipError_t le = hipErrorInvalidValue;
+        {
+            SkmProfScope ps(ctx, "k_bw_team", st);
+#define SKM_TEAM_LAUNCH(NJT_, B_)                                                                                  \
+    do {                                                                                                          \
+        if ((rc = set_lds(k_seg_team<4, NJT_, B_, true>, p.team_lds))) return rc;                               \
+        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_seg_team<4, NJT_, B_, true>),          \
+                                        dim3(p.team_wgs), dim3(256), kargs, (unsigned)p.team_lds, st);            \
+    } while (0)
+            if (p.g.NJT == 1) {
+                if (p.team_B == 2) SKM_TEAM_LAUNCH(1, 2);
+                else if (p.team_B == 4) SKM_TEAM_LAUNCH(1, 4);
+                else if (p.team_B == 8) SKM_TEAM_LAUNCH(1, 8);
+            } else {
+                if (p.team_B == 2) SKM_TEAM_LAUNCH(2, 2);
+                else if (p.team_B == 4) SKM_TEAM_LAUNCH(2, 4);
+                else if (p.team_B == 8) SKM_TEAM_LAUNCH(2, 8);
+            }
+#undef SKM_TEAM_LAUNCH
+        }
+        if (le == hipSuccess) return SKM_OK;
+        (void)hipGetLastError();   // the teams cannot all be resident on this device: two sweeps instead
+    }
     if ((rc = launch_lse(ctx, p, X, T, wp, kc, ws, nullptr, st))) return rc;
     StatsArgs a;
     memset(&a, 0, sizeof(a));

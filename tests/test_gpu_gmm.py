@@ -151,6 +151,37 @@ def test_bw_stats_ragged_and_empty_sessions(eng):
     assert np.allclose(s0.sum(1), lens, rtol=1e-4)
 
 
+@pytest.mark.parametrize("C,D", [(1024, 60), (2048, 20), (4096, 60)])
+def test_bw_stats_team_kernel_ragged_and_empty_sessions(eng, C, D):
+    """C = 1024 / 2048 / 4096 takes the single-sweep team kernel in Baum-Welch mode (one pipeline segment per
+    session, sessions cut over the teams by frame count): empty sessions at the start, in the middle, at a
+    team boundary and at the end, one-frame and non-multiple-of-32 sessions, more teams than sessions' tiles;
+    cross-checked against the two-sweep path (SKM_TEAM=0) too."""
+    import os
+    gmm = orc.random_gmm(C, D, seed=9)
+    lens = [0, 0, 1, 31, 32, 33, 0, 257, 64, 1, 0, 700, 95, 0, 0]
+    frames = orc.synth_frames(sum(lens), dim=D, seed=10)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    X = eng.upload_frames(frames)
+    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    s0, s1 = eng.bw_stats(X, off, packed)
+    s0, s1 = eng.to_host(s0), eng.to_host(s1)
+    r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
+    assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
+    for i, n in enumerate(lens):
+        if n == 0:
+            assert np.all(s0[i] == 0) and np.all(s1[i] == 0)
+        else:
+            assert rel(s0[i], r0[i]) < TOL and rel(s1[i], r1[i]) < TOL
+    assert np.allclose(s0.sum(1), lens, rtol=1e-4)
+    os.environ["SKM_TEAM"] = "0"
+    try:
+        t0, t1 = eng.bw_stats(X, off, packed)
+    finally:
+        del os.environ["SKM_TEAM"]
+    assert rel(s0, eng.to_host(t0)) < 2e-5 and rel(s1, eng.to_host(t1)) < 2e-5
+
+
 def test_statserver_accumulate_stat_dropin(sk):
     g = golden("accumulate_stat.npz")
     sess, off = _sessions(g)
