@@ -2479,7 +2479,7 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         p->team_B = B;
         p->team_per_xcd = (B > 0) ? (wgs / 8) / B : 0;
         p->team_wgs = 8 * p->team_per_xcd * B;
-        p->team = (g.CT == g.CTpad && g.CTpad % 16 == 0 && (B == 2 || B == 4 || B == 8) && p->team_per_xcd >= 1 &&
+        p->team = (g.CT == g.CTpad && g.CTpad % 16 == 0 && (B == 1 || B == 2 || B == 4 || B == 8) && p->team_per_xcd >= 1 &&
                    D % 4 == 0 && D <= 64 && g.NJT <= 2 && (e ? atoi(e) != 0 : 1)) ? 1 : 0;
         p->team_lds = ((size_t)4 * 32 * g.XS + 4 * 32 + (size_t)4 * 4 * 4 * 64 * 4) * sizeof(float);
     }
@@ -2693,7 +2693,7 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
         SKM_HIP(hipGetLastError());
         return SKM_OK;
     }
-    if (p.team) {
+    if (p.team && p.team_B >= 2) {
         TeamArgs t;
         t.X = X;
         t.T = T;
@@ -2859,11 +2859,13 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
                                         dim3(p.team_wgs), dim3(256), kargs, (unsigned)p.team_lds, st);            \
     } while (0)
             if (p.g.NJT == 1) {
-                if (p.team_B == 2) SKM_TEAM_LAUNCH(1, 2);
+                if (p.team_B == 1) SKM_TEAM_LAUNCH(1, 1);
+                else if (p.team_B == 2) SKM_TEAM_LAUNCH(1, 2);
                 else if (p.team_B == 4) SKM_TEAM_LAUNCH(1, 4);
                 else if (p.team_B == 8) SKM_TEAM_LAUNCH(1, 8);
             } else {
-                if (p.team_B == 2) SKM_TEAM_LAUNCH(2, 2);
+                if (p.team_B == 1) SKM_TEAM_LAUNCH(2, 1);
+                else if (p.team_B == 2) SKM_TEAM_LAUNCH(2, 2);
                 else if (p.team_B == 4) SKM_TEAM_LAUNCH(2, 4);
                 else if (p.team_B == 8) SKM_TEAM_LAUNCH(2, 8);
             }

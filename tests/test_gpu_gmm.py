@@ -151,7 +151,7 @@ def test_bw_stats_ragged_and_empty_sessions(eng):
     assert np.allclose(s0.sum(1), lens, rtol=1e-4)
 
 
-@pytest.mark.parametrize("C,D", [(1024, 60), (2048, 20), (4096, 60)])
+@pytest.mark.parametrize("C,D", [(512, 60), (1024, 60), (2048, 20), (4096, 60)])
 def test_bw_stats_team_kernel_ragged_and_empty_sessions(eng, C, D):
     """C = 1024 / 2048 / 4096 takes the single-sweep team kernel in Baum-Welch mode (one pipeline segment per
     session, sessions cut over the teams by frame count): empty sessions at the start, in the middle, at a
@@ -179,7 +179,7 @@ def test_bw_stats_team_kernel_ragged_and_empty_sessions(eng, C, D):
         t0, t1 = eng.bw_stats(X, off, packed)
     finally:
         del os.environ["SKM_TEAM"]
-    assert rel(s0, eng.to_host(t0)) < 2e-5 and rel(s1, eng.to_host(t1)) < 2e-5
+    assert rel(s0, eng.to_host(t0)) < 5e-5 and rel(s1, eng.to_host(t1)) < 5e-5   # two float32 paths, each within 1e-4 of the oracle
 
 
 def test_statserver_accumulate_stat_dropin(sk):
