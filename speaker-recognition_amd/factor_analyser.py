@@ -143,10 +143,26 @@ class FactorAnalyser(object):
         if ft is not None:
             eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, A_aug=A_aug, Cacc=Cacc)
         del G
-        dist.allreduce_sum_(A_aug)
-        dist.allreduce_sum_(Cacc)
-        r_sum = eng.to_host(A_aug[C]).reshape(R, R)
-        F_new = eng.tv_mstep(A_aug, Cacc, C, D, R)
+        world = dist.world_size()
+        sharded = world > 1 and C % world == 0
+        if sharded:
+            # component-sharded M-step: reduce-scatter the accumulators so that rank g owns
+            # components [g*C/W, (g+1)*C/W), all-reduce only _R (R*R doubles), solve locally, all-gather F rows.
+            Cl = C // world
+            r_dev = A_aug[C].clone()
+            dist.allreduce_sum_(r_dev)
+            r_sum = eng.to_host(r_dev).reshape(R, R)
+            A_loc = dist.reduce_scatter_rows(A_aug[:C])
+            del A_aug
+            C_loc = dist.reduce_scatter_rows(
+                Cacc.view(R, world, Cl * D).permute(1, 0, 2).contiguous().view(world * R, Cl * D))
+            del Cacc
+            F_new = eng.tv_mstep(A_loc, C_loc, Cl, D, R)
+        else:
+            dist.allreduce_sum_(A_aug)
+            dist.allreduce_sum_(Cacc)
+            r_sum = eng.to_host(A_aug[C]).reshape(R, R)
+            F_new = eng.tv_mstep(A_aug, Cacc, C, D, R)
         if min_div:
             # _R / nb_sessions, symmetric from its upper triangle; upper Cholesky factor
             # (scipy.linalg.cholesky default, factor_analyser.py:661-665).  One R x R matrix per iteration.
@@ -154,6 +170,8 @@ class FactorAnalyser(object):
             r_bar = (up + np.triu(r_sum, 1).T) / float(total_sessions)
             ch = np.linalg.cholesky(r_bar).T
             F_new = eng.gemm(F_new, torch.from_numpy(np.ascontiguousarray(ch)).to(eng.device))
+        if sharded:
+            F_new = dist.allgather_rows(F_new, [F_new.shape[0]] * world)
         return F_new
 
     def _train(self, sources, ubm, tv_rank, nb_iter, min_div, tv_init, batch_size, save_init, output_file_name,

@@ -87,7 +87,7 @@ class OracleEngine(object):
         return torch.from_numpy(e_h), (torch.from_numpy(sig) if uncertainty else None)
 
     def tv_mstep(self, A_aug, Cacc, C, D, R, batch=128):
-        A = A_aug.numpy().reshape(C + 1, R, R)
+        A = A_aug.numpy().reshape(-1, R, R)
         Cc = Cacc.numpy()
         Fm = np.zeros((C * D, R))
         for c in range(C):
