@@ -195,6 +195,47 @@ __global__ __launch_bounds__(256) void k_tv_finish(const double *__restrict__ Li
     }
 }
 
+// Extraction only: e_h = X (X' aux) and diag(L^-1) = row norms^2 of X, with X = U^-1 (upper triangular) left by
+// the blocked inverse -- the R^3 product X X' is never formed when no accumulator needs L^-1 itself.
+__global__ __launch_bounds__(256) void k_tv_finish_tri(const double *__restrict__ X, int R, const double *__restrict__ aux,
+                                                       double *__restrict__ e_h, float *__restrict__ e_h32,
+                                                       double *__restrict__ iv_sigma)
+{
+    extern __shared__ double sh[];  // aux[R], y[R]
+    double *ax = sh, *y = sh + R;
+    const long b = blockIdx.x;
+    const double *Xi = X + b * (long)R * R;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < R; i += 256) ax[i] = aux[b * R + i];
+    __syncthreads();
+    // y = X' aux: y[j] = sum_{i<=j} X[i][j] aux[i]   (column sweep, coalesced along j)
+    for (int j = t; j < R; j += 256) {
+        double s = 0.0;
+        for (int i = 0; i <= j; ++i) s += Xi[(long)i * R + j] * ax[i];
+        y[j] = s;
+    }
+    __syncthreads();
+    // e_h[i] = sum_{j>=i} X[i][j] y[j], diag[i] = sum_{j>=i} X[i][j]^2   (row reduce, one wave per row)
+    for (int i = wave; i < R; i += 4) {
+        double s = 0.0, d = 0.0;
+        for (int j = i + lane; j < R; j += 64) {
+            const double x = Xi[(long)i * R + j];
+            s += x * y[j];
+            d += x * x;
+        }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            s += __shfl_xor(s, m);
+            d += __shfl_xor(d, m);
+        }
+        if (lane == 0) {
+            e_h[b * R + i] = s;
+            if (e_h32) e_h32[b * R + i] = (float)s;
+            if (iv_sigma) iv_sigma[b * R + i] = d + s * s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------
@@ -244,6 +285,7 @@ static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int
         x.sB = (long)TV_BLK * R;
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, x, nb, st, "k_gemm_trinv_b"))) return rc;
     }
+    if (!out) return SKM_OK;   // the caller works with X = U^-1 itself
     // M^-1 = X X'
     GemmArgs p = skm_gemm_args(Mb, Mb, out, R, R, R, R, R, R);
     p.transB = 1;
@@ -397,8 +439,12 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         l.colmap = cmap;
         l.colmap_vec = (R % 4 == 0);
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, l, 1, st, "k_gemm_lbuild"))) return rc;
-        if ((rc = blocked_inverse(ctx, Mb, Linv, Tb, nb, R, 1, 1, st))) return rc;
-        {
+        if ((rc = blocked_inverse(ctx, Mb, train ? Linv : nullptr, Tb, nb, R, 1, 1, st))) return rc;
+        if (!train) {
+            SkmProfScope ps(ctx, "k_tv_finish", st);
+            hipLaunchKernelGGL(k_tv_finish_tri, dim3(nb), dim3(256), 2 * R * sizeof(double), st, Mb, R, aux + b0 * R,
+                               e_h + b0 * R, eh32 + b0 * R, iv_sigma ? iv_sigma + b0 * R : nullptr);
+        } else {
             SkmProfScope ps(ctx, "k_tv_finish", st);
             hipLaunchKernelGGL(k_tv_finish, dim3(nb), dim3(256), 2 * R * sizeof(double), st, Linv, R, aux + b0 * R,
                                e_h + b0 * R, eh32 + b0 * R, iv_sigma ? iv_sigma + b0 * R : nullptr,
@@ -445,14 +491,22 @@ extern "C" int skm_tv_mstep(void *ctx_, double *A_aug, const double *Cacc, int C
     int rc;
     for (int c0 = 0; c0 < C; c0 += batch) {
         const int nb = (C - c0) < batch ? (C - c0) : batch;
-        if ((rc = blocked_inverse(ctx, A_aug + c0 * RR, Linv, Tb, nb, R, 0, 0, st))) return rc;
-        // T_c[d][r] = sum_k C[k][cD+d] A_c^-1[k][r]
-        GemmArgs g = skm_gemm_args(Cacc + (long)c0 * D, Linv, F_out + (long)c0 * D * R, D, R, R, CD, R, R);
-        g.transA = 1;
+        // A_c^-1 = X X' with X = U^-1 (upper triangular, left in place of A_c): T_c = (C_c' X) X' is two D x R x R
+        // products per component instead of the R^3 product X X' plus one
+        if ((rc = blocked_inverse(ctx, A_aug + c0 * RR, nullptr, Tb, nb, R, 0, 0, st))) return rc;
+        double *Y = Linv;   // [nb][D][R]
+        GemmArgs g = skm_gemm_args(Cacc + (long)c0 * D, A_aug + c0 * RR, Y, D, R, R, CD, R, R);
+        g.transA = 1;       // Y[d][r] = sum_k C[k][cD+d] X[k][r]
         g.sA = D;
         g.sB = RR;
         g.sC = (long)D * R;
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, g, nb, st, "k_gemm_mstep"))) return rc;
+        GemmArgs t = skm_gemm_args(Y, A_aug + c0 * RR, F_out + (long)c0 * D * R, D, R, R, R, R, R);
+        t.transB = 1;       // T_c[d][r] = sum_j Y[d][j] X[r][j]
+        t.sA = (long)D * R;
+        t.sB = RR;
+        t.sC = (long)D * R;
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, t, nb, st, "k_gemm_mstep"))) return rc;
     }
     return SKM_OK;
 }

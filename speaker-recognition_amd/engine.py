@@ -316,7 +316,7 @@ class HipEngine(object):
                                           _c_void_p(ws), need, self._stream()))
         return e_h, sig
 
-    def tv_mstep(self, A_aug, Cacc, C, D, R, batch=128):
+    def tv_mstep(self, A_aug, Cacc, C, D, R, batch=1024):
         """New loading matrix (CD x R float64) from the accumulators; A_aug[0:C] is destroyed."""
         torch = self.torch
         batch = int(max(1, min(batch, C)))
