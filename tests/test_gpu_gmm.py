@@ -309,3 +309,59 @@ def test_team_kernel_matches_two_sweeps_and_accumulates(eng):
     out = eng.estep(X, packed)
     out = eng.estep(X, packed, out=out, accumulate=True)
     np.testing.assert_allclose(eng.to_host(out), 2.0 * a, rtol=1e-12)
+
+
+def test_full_size_invariants_cfg2(eng):
+    """BASELINE configs[1] at full size (C=512, D=60, 10 M frames resident in HBM) through size-independent
+    properties of the statistics: sum_c N_c = T, sum_c F_c = sum_t x_t, sum_c S_c = sum_t x_t^2 (posteriors
+    sum to one per frame), bit-identical repeat, and a 1/64 sub-sample cross-checked against the oracle."""
+    import torch
+    C, D, T = 512, 60, 10_000_000
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(99)
+    X = torch.randn(T, D, generator=g, device=eng.device, dtype=torch.float32)
+    gmm = orc.random_gmm(C, D, seed=21)
+    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    out = eng.to_host(eng.estep(X, packed))
+    N, F, S, llk = unpack(out, C, D)
+    assert np.isfinite(out).all()
+    assert abs(N.sum() - T) < 2e-5 * T     # float32 posteriors: v_exp_f32 / v_rcp_f32 are 1-ulp instructions
+    mom = np.asarray(eng.to_host(eng.moments(X)))
+    m1, m2 = mom[:D], mom[D:]
+    assert np.abs(F.sum(0) - m1).max() < 1e-5 * np.abs(m2).max()
+    assert rel(S.sum(0), m2) < 1e-5
+    np.testing.assert_array_equal(out, eng.to_host(eng.estep(X, packed)))
+    sub = X[::64].contiguous()
+    Ns, Fs, Ss, ls = unpack(eng.to_host(eng.estep(sub, packed)), C, D)
+    rN, rF, rS, rl = orc.expectation(gmm, sub.cpu().numpy().astype(np.float64))
+    assert rel(Ns, rN) < TOL and rel(Fs, rF) < TOL and rel(Ss, rS) < TOL and abs(ls - rl) < 1e-5 * abs(rl)
+
+
+def test_full_size_invariants_cfg3_cfg4_shape(eng):
+    """C=2048 at a per-GPU shard size of configs[2]/[3] (4 M frames, 2000 sessions x 2000 frames): the
+    single-sweep team kernels.  EM: sum_c N_c = T and the first/second moment identities; Baum-Welch: every
+    stat0 row sums to its session length, stat1 rows sum over components to the session's sum of frames,
+    and the session statistics add up to the EM statistics of the same frames."""
+    import torch
+    C, D, S, L = 2048, 60, 2000, 2000
+    T = S * L
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(7)
+    X = torch.randn(T, D, generator=g, device=eng.device, dtype=torch.float32)
+    gmm = orc.random_gmm(C, D, seed=22)
+    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    N, F, Sx, llk = unpack(eng.to_host(eng.estep(X, packed)), C, D)
+    assert abs(N.sum() - T) < 2e-5 * T     # float32 posteriors: v_exp_f32 / v_rcp_f32 are 1-ulp instructions
+    mom = np.asarray(eng.to_host(eng.moments(X)))
+    m1, m2 = mom[:D], mom[D:]
+    assert np.abs(F.sum(0) - m1).max() < 1e-5 * np.abs(m2).max()
+    assert rel(Sx.sum(0), m2) < 1e-5
+    seg = torch.arange(0, S + 1, dtype=torch.int64, device=eng.device) * L
+    s0, s1 = eng.bw_stats(X, seg, packed)
+    rows = s0.sum(1).cpu().numpy()
+    assert np.abs(rows - L).max() < 2e-5 * L
+    assert rel(s0.sum(0).cpu().numpy(), N) < 1e-5
+    assert rel(s1.sum(0).cpu().numpy().reshape(C, D), F) < 1e-5
+    sess_sum = X[:L].double().sum(0).cpu().numpy()
+    got = s1[0].cpu().numpy().reshape(C, D).sum(0)
+    assert np.abs(got - sess_sum).max() < 1e-4 * np.abs(sess_sum).max() + 1e-3
