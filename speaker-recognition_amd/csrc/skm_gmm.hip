@@ -1202,7 +1202,7 @@ __device__ __forceinline__ void wset_tail_pf(f32x16 (&lg)[NCT], const f32x4 (&wl
 
 // lg += [x, x^2] . W with W streamed from L2; `wa` must already hold pair 0 on entry (requested during the
 // previous tile) and holds pair 0 again on return.
-template <int NCT>
+template <int NCT, int GEO = -1>
 __device__ __forceinline__ void gemm_logits_fat(f32x16 (&lg)[NCT], WSet<NCT> &wa, const float *xs_row, int h,
                                                 const WStream &Wg4, const TileGeom &g, long long *tr = nullptr)
 {
@@ -1230,15 +1230,19 @@ __device__ __forceinline__ void gemm_logits_fat(f32x16 (&lg)[NCT], WSet<NCT> &wa
 #ifdef SKM_TRACE
     if (tr) tr[11] = __builtin_readcyclecounter();
 #endif
-    if (q < NP) {   // odd pair count: pair q sits in wa, the tail group goes to wb
+    // GEO >= 0: pair-count parity (bit 1) and tail group (bit 0) are compile-time, so this ending is straight-line
+    // code (the runtime form costs ~150 register copies per tile where its four branches merge)
+    const bool odd = (GEO >= 0) ? ((GEO & 2) != 0) : (q < NP);
+    const bool tail = (GEO >= 0) ? ((GEO & 1) != 0) : (g.tail != 0);
+    if (odd) {      // pair q sits in wa, the tail group goes to wb
         wset_mma_pf<NCT>(lg, wa, xa, wb, Wg4, NG, NP, q + 1);
-        if (g.tail)
+        if (tail)
             wset_tail_pf<NCT, true>(lg, wb.l, xt, wa, Wg4, NG);
         else
             wset_tail_pf<NCT, false>(lg, wb.l, xt, wa, Wg4, NG);
-    } else {        // even pair count: wa holds the tail group
+    } else {        // wa holds the tail group
         WSet<NCT> w0;
-        if (g.tail)
+        if (tail)
             wset_tail_pf<NCT, true>(lg, wa.l, xt, w0, Wg4, NG);
         else
             wset_tail_pf<NCT, false>(lg, wa.l, xt, w0, Wg4, NG);
@@ -1306,7 +1310,7 @@ __device__ __forceinline__ void flush_slab_agpr(f32x16 (&acc)[NCT][NF], double *
         }
 }
 
-template <int NCT, int NJT>
+template <int NCT, int NJT, int GEO>
 __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
 {
     constexpr int NF = 2 * NJT, NFW = NF * 32, PRE = 8;
@@ -1453,9 +1457,9 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
 #ifdef SKM_TRACE
-        gemm_logits_fat<NCT>(lg, wa, xt + c * g.XS, h, Wg4, g, trace_now ? a.trace + wave * 16 : nullptr);
+        gemm_logits_fat<NCT, GEO>(lg, wa, xt + c * g.XS, h, Wg4, g, trace_now ? a.trace + wave * 16 : nullptr);
 #else
-        gemm_logits_fat<NCT>(lg, wa, xt + c * g.XS, h, Wg4, g);
+        gemm_logits_fat<NCT, GEO>(lg, wa, xt + c * g.XS, h, Wg4, g);
 #endif
         SKM_STAMP(1);
 
@@ -1658,7 +1662,7 @@ struct TeamArgs {
 // EM statistics: the team's tiles in one run, slabs folded every SKM_FLUSH_TILES tiles.  (k_seg_team below is
 // the same pipeline cut into segments with a flush per segment -- one session each -- for Baum-Welch; its
 // EM instantiation allocates registers worse than this dedicated kernel, 50 vs 36 ms at C=2048, so both stay.)
-template <int NCT, int NJT, int B>
+template <int NCT, int NJT, int B, int GEO>
 __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
 {
     constexpr int NF = 2 * NJT, NFW = NF * 32, PRE = 8, RING = 4;
@@ -1833,7 +1837,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
             }
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
-            gemm_logits_fat<NCT>(lg, wa, xt + c * g.XS, h, Wg4, g);
+            gemm_logits_fat<NCT, GEO>(lg, wa, xt + c * g.XS, h, Wg4, g);
             SKM_STAMP(1);
             if (tile > ta) poll_issue(tile - 1);
 
@@ -1937,7 +1941,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
     }
 }
 
-template <int NCT, int NJT, int B, bool BW>
+template <int NCT, int NJT, int B, bool BW, int GEO>
 __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
 {
     constexpr int NF = BW ? NJT : 2 * NJT, NFW = NF * 32, PRE = 8, RING = 4, NC = 4 * B;
@@ -2112,7 +2116,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
             }
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
-            gemm_logits_fat<NCT>(lg, wa, xt + c * g.XS, h, Wg4, g);
+            gemm_logits_fat<NCT, GEO>(lg, wa, xt + c * g.XS, h, Wg4, g);
             SKM_STAMP(1);
             if (i > 0) poll_issue(ni - 1);
 
@@ -2670,13 +2674,24 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
         {
             SkmProfScope ps(ctx, fat ? "k_estep_fat" : "k_estep_fused", st);
             if (fat) {
+                const int geo = ((p.tg.NP & 1) ? 2 : 0) | (p.tg.tail ? 1 : 0);
+#define SKM_FAT_LAUNCH(NJT_, GEO_)                                                                       \
+    do {                                                                                                \
+        if ((rc = set_lds(k_estep_fat<4, NJT_, GEO_>, p.fused_lds))) return rc;                         \
+        hipLaunchKernelGGL((k_estep_fat<4, NJT_, GEO_>), dim3(nblk), dim3(64 * nwv), p.fused_lds, st, f); \
+    } while (0)
                 if (p.g.NJT == 1) {
-                    if ((rc = set_lds(k_estep_fat<4, 1>, p.fused_lds))) return rc;
-                    hipLaunchKernelGGL((k_estep_fat<4, 1>), dim3(nblk), dim3(64 * nwv), p.fused_lds, st, f);
+                    if (geo == 0) SKM_FAT_LAUNCH(1, 0);
+                    else if (geo == 1) SKM_FAT_LAUNCH(1, 1);
+                    else if (geo == 2) SKM_FAT_LAUNCH(1, 2);
+                    else SKM_FAT_LAUNCH(1, 3);
                 } else {
-                    if ((rc = set_lds(k_estep_fat<4, 2>, p.fused_lds))) return rc;
-                    hipLaunchKernelGGL((k_estep_fat<4, 2>), dim3(nblk), dim3(64 * nwv), p.fused_lds, st, f);
+                    if (geo == 0) SKM_FAT_LAUNCH(2, 0);
+                    else if (geo == 1) SKM_FAT_LAUNCH(2, 1);
+                    else if (geo == 2) SKM_FAT_LAUNCH(2, 2);
+                    else SKM_FAT_LAUNCH(2, 3);
                 }
+#undef SKM_FAT_LAUNCH
             } else if (p.g.NJT == 1) {
                 if ((rc = set_lds(k_estep_fused<1>, p.fused_lds))) return rc;
                 hipLaunchKernelGGL(k_estep_fused<1>, dim3(nblk), dim3(64 * nwv), p.fused_lds, st, f);
@@ -2723,22 +2738,31 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
         hipError_t le;
         {
             SkmProfScope ps(ctx, "k_estep_team", st);
-#define SKM_TEAM_LAUNCH(NJT_, B_)                                                                                  \
+#define SKM_TEAM_LAUNCH(NJT_, B_, GEO_)                                                                            \
     do {                                                                                                          \
-        if ((rc = set_lds(k_estep_team<4, NJT_, B_>, p.team_lds))) return rc;                              \
-        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_estep_team<4, NJT_, B_>),         \
+        if ((rc = set_lds(k_estep_team<4, NJT_, B_, GEO_>, p.team_lds))) return rc;                               \
+        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_estep_team<4, NJT_, B_, GEO_>),          \
                                         dim3(p.team_wgs), dim3(256), kargs, (unsigned)p.team_lds, st);            \
     } while (0)
+#define SKM_TEAM_GEO(B_)                                                                                           \
+    do {                                                                                                          \
+        if (geo == 0) SKM_TEAM_LAUNCH(2, B_, 0);                                                                  \
+        else if (geo == 1) SKM_TEAM_LAUNCH(2, B_, 1);                                                             \
+        else if (geo == 2) SKM_TEAM_LAUNCH(2, B_, 2);                                                             \
+        else SKM_TEAM_LAUNCH(2, B_, 3);                                                                           \
+    } while (0)
             le = hipErrorInvalidValue;
-            if (p.g.NJT == 1) {
-                if (p.team_B == 2) SKM_TEAM_LAUNCH(1, 2);
-                else if (p.team_B == 4) SKM_TEAM_LAUNCH(1, 4);
-                else if (p.team_B == 8) SKM_TEAM_LAUNCH(1, 8);
+            const int geo = ((p.tg.NP & 1) ? 2 : 0) | (p.tg.tail ? 1 : 0);
+            if (p.g.NJT == 1) {     // D < 32: geometry stays a run-time branch (fewer instantiations)
+                if (p.team_B == 2) SKM_TEAM_LAUNCH(1, 2, -1);
+                else if (p.team_B == 4) SKM_TEAM_LAUNCH(1, 4, -1);
+                else if (p.team_B == 8) SKM_TEAM_LAUNCH(1, 8, -1);
             } else {
-                if (p.team_B == 2) SKM_TEAM_LAUNCH(2, 2);
-                else if (p.team_B == 4) SKM_TEAM_LAUNCH(2, 4);
-                else if (p.team_B == 8) SKM_TEAM_LAUNCH(2, 8);
+                if (p.team_B == 2) SKM_TEAM_GEO(2);
+                else if (p.team_B == 4) SKM_TEAM_GEO(4);
+                else if (p.team_B == 8) SKM_TEAM_GEO(8);
             }
+#undef SKM_TEAM_GEO
 #undef SKM_TEAM_LAUNCH
         }
         if (le == hipSuccess) {
@@ -2852,23 +2876,32 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
         hipError_t le = hipErrorInvalidValue;
         {
             SkmProfScope ps(ctx, "k_bw_team", st);
-#define SKM_TEAM_LAUNCH(NJT_, B_)                                                                                  \
+#define SKM_TEAM_LAUNCH(NJT_, B_, GEO_)                                                                            \
     do {                                                                                                          \
-        if ((rc = set_lds(k_seg_team<4, NJT_, B_, true>, p.team_lds))) return rc;                               \
-        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_seg_team<4, NJT_, B_, true>),          \
+        if ((rc = set_lds(k_seg_team<4, NJT_, B_, true, GEO_>, p.team_lds))) return rc;                           \
+        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_seg_team<4, NJT_, B_, true, GEO_>),      \
                                         dim3(p.team_wgs), dim3(256), kargs, (unsigned)p.team_lds, st);            \
     } while (0)
+#define SKM_TEAM_GEO(B_)                                                                                           \
+    do {                                                                                                          \
+        if (geo == 0) SKM_TEAM_LAUNCH(2, B_, 0);                                                                  \
+        else if (geo == 1) SKM_TEAM_LAUNCH(2, B_, 1);                                                             \
+        else if (geo == 2) SKM_TEAM_LAUNCH(2, B_, 2);                                                             \
+        else SKM_TEAM_LAUNCH(2, B_, 3);                                                                           \
+    } while (0)
+            const int geo = ((p.tg.NP & 1) ? 2 : 0) | (p.tg.tail ? 1 : 0);
             if (p.g.NJT == 1) {
-                if (p.team_B == 1) SKM_TEAM_LAUNCH(1, 1);
-                else if (p.team_B == 2) SKM_TEAM_LAUNCH(1, 2);
-                else if (p.team_B == 4) SKM_TEAM_LAUNCH(1, 4);
-                else if (p.team_B == 8) SKM_TEAM_LAUNCH(1, 8);
+                if (p.team_B == 1) SKM_TEAM_LAUNCH(1, 1, -1);
+                else if (p.team_B == 2) SKM_TEAM_LAUNCH(1, 2, -1);
+                else if (p.team_B == 4) SKM_TEAM_LAUNCH(1, 4, -1);
+                else if (p.team_B == 8) SKM_TEAM_LAUNCH(1, 8, -1);
             } else {
-                if (p.team_B == 1) SKM_TEAM_LAUNCH(2, 1);
-                else if (p.team_B == 2) SKM_TEAM_LAUNCH(2, 2);
-                else if (p.team_B == 4) SKM_TEAM_LAUNCH(2, 4);
-                else if (p.team_B == 8) SKM_TEAM_LAUNCH(2, 8);
+                if (p.team_B == 1) SKM_TEAM_GEO(1);
+                else if (p.team_B == 2) SKM_TEAM_GEO(2);
+                else if (p.team_B == 4) SKM_TEAM_GEO(4);
+                else if (p.team_B == 8) SKM_TEAM_GEO(8);
             }
+#undef SKM_TEAM_GEO
 #undef SKM_TEAM_LAUNCH
         }
         if (le == hipSuccess) return SKM_OK;
