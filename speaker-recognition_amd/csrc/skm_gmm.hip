@@ -1310,10 +1310,10 @@ __device__ __forceinline__ void flush_slab_agpr(f32x16 (&acc)[NCT][NF], double *
         }
 }
 
-template <int NCT, int NJT, int GEO>
+template <int NCT, int NJT, int GEO, int PRE>
 __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
 {
-    constexpr int NF = 2 * NJT, NFW = NF * 32, PRE = 8;
+    constexpr int NF = 2 * NJT, NFW = NF * 32;   // PRE = floats staged per thread: 8 (4 waves) or 16 (2 waves)
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, NWV = nthr >> 6;
@@ -2469,7 +2469,7 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         const int fw = g.CTpad / 4;
         const char *e = getenv("SKM_FAT");
         // 3 waves would leave one SIMD of the CU idle (a 512-register wave owns its SIMD): 2 or 4 only
-        p->fused_fat = (p->fused && (fw == 2 || fw == 4) && 32 * g.D <= 8 * 64 * fw && (e ? atoi(e) != 0 : 1)) ? 1 : 0;
+        p->fused_fat = (p->fused && (fw == 2 || fw == 4) && 32 * g.D <= 2048 && (e ? atoi(e) != 0 : 1)) ? 1 : 0;
         p->fat_blocks = wgs * (fw <= 2 ? 2 : 1);
         if (p->fat_blocks > p->n_llk) p->fat_blocks = p->n_llk;
     }
@@ -2675,10 +2675,15 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
             SkmProfScope ps(ctx, fat ? "k_estep_fat" : "k_estep_fused", st);
             if (fat) {
                 const int geo = ((p.tg.NP & 1) ? 2 : 0) | (p.tg.tail ? 1 : 0);
-#define SKM_FAT_LAUNCH(NJT_, GEO_)                                                                       \
-    do {                                                                                                \
-        if ((rc = set_lds(k_estep_fat<4, NJT_, GEO_>, p.fused_lds))) return rc;                         \
-        hipLaunchKernelGGL((k_estep_fat<4, NJT_, GEO_>), dim3(nblk), dim3(64 * nwv), p.fused_lds, st, f); \
+#define SKM_FAT_LAUNCH(NJT_, GEO_)                                                                              \
+    do {                                                                                                       \
+        if (nwv == 4) {                                                                                        \
+            if ((rc = set_lds(k_estep_fat<4, NJT_, GEO_, 8>, p.fused_lds))) return rc;                         \
+            hipLaunchKernelGGL((k_estep_fat<4, NJT_, GEO_, 8>), dim3(nblk), dim3(256), p.fused_lds, st, f);    \
+        } else {                                                                                               \
+            if ((rc = set_lds(k_estep_fat<4, NJT_, GEO_, 16>, p.fused_lds))) return rc;                        \
+            hipLaunchKernelGGL((k_estep_fat<4, NJT_, GEO_, 16>), dim3(nblk), dim3(128), p.fused_lds, st, f);   \
+        }                                                                                                      \
     } while (0)
                 if (p.g.NJT == 1) {
                     if (geo == 0) SKM_FAT_LAUNCH(1, 0);
