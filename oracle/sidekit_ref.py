@@ -410,3 +410,41 @@ def random_gmm(C, D, seed=7):
     mu = rs.randn(C, D)
     var = rs.uniform(0.5, 1.5, size=(C, D))
     return GMM(w, mu, 1.0 / var)
+
+
+# ----------------------------------------------------------------------------------------
+# next row: MAP mean adaptation and GMM-UBM log-likelihood-ratio scoring
+# ----------------------------------------------------------------------------------------
+def adapt_mean_map_multisession(gmm, modelset, stat0, stat1, r=16.0):
+    """MAP-adapted mean super-vectors, one per unique model, statistics summed over the model's sessions
+    (sidekit/statserver.py:986-1028 with norm=False, sum_stat_per_model :1206-1226).
+    Returns (unique model names, M[n_models x C*D])."""
+    modelset = np.asarray(modelset)
+    models = np.unique(modelset)
+    C, D = gmm.C, gmm.D
+    index_map = np.repeat(np.arange(C), D)
+    s0 = np.stack([np.asarray(stat0, dtype=F64)[modelset == m].sum(0) for m in models])
+    s1 = np.stack([np.asarray(stat1, dtype=F64)[modelset == m].sum(0) for m in models])
+    alpha = s0 / (s0 + r)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        M = s1 / s0[:, index_map]
+    M[np.isnan(M)] = 0.0
+    M = alpha[:, index_map] * M + (1.0 - alpha[:, index_map]) * np.tile(gmm.mu.reshape(-1), (M.shape[0], 1))
+    return models, M
+
+
+def gmm_scoring(gmm, enroll_modelset, enroll_means, ndx_modelset, ndx_segset, trialmask, segments):
+    """Mean per-frame log-likelihood ratio of every trial (sidekit/gmm_scoring.py:56-119): model = UBM with the
+    enrolled mean super-vector, denominator = the UBM.  `segments` maps a segment name to its T x D frames.
+    Untested cells stay 0."""
+    enroll_modelset = list(np.asarray(enroll_modelset))
+    scores = np.zeros(np.asarray(trialmask).shape, dtype=F64)
+    for ts, seg in enumerate(np.asarray(ndx_segset)):
+        cep = np.asarray(segments[str(seg)], dtype=F64)
+        ubm_llk = logsumexp_rows(log_posterior(gmm, cep))[1].mean()
+        for mi, model in enumerate(np.asarray(ndx_modelset)):
+            if not trialmask[mi, ts] or model not in enroll_modelset:
+                continue
+            mu = enroll_means[enroll_modelset.index(model)]
+            scores[mi, ts] = logsumexp_rows(log_posterior(gmm, cep, mu=mu))[1].mean() - ubm_llk
+    return scores

@@ -142,3 +142,20 @@ def test_whiten_f64_matches_single_path():
         L = np.eye(R) + (Fm.T * s0[i, idx]).dot(Fm)
         iv[i] = np.linalg.solve(L, Fm.T.dot(w[i]))
     close(iv, g["iv_single"], rtol=1e-9)
+
+
+def test_map_adaptation_and_gmm_scoring_vs_reference_golden():
+    """adapt_mean_map_multisession (statserver.py:986-1028) and gmm_scoring_singleThread
+    (gmm_scoring.py:56-119) of the real reference."""
+    g = golden("gmm_scoring.npz")
+    gmm = orc.GMM(g["w"], g["mu"], g["invcov"])
+    off = np.concatenate([[0], np.cumsum(g["enr_lens"])])
+    sess = [g["enr_frames"][off[i]:off[i + 1]] for i in range(len(g["enr_lens"]))]
+    s0, s1 = orc.accumulate_stat(gmm, sess)
+    models, M = orc.adapt_mean_map_multisession(gmm, g["enr_spk"], s0, s1, r=16)
+    assert list(models) == list(g["enroll_modelset"])
+    np.testing.assert_allclose(M, g["enroll_stat1"], rtol=1e-10, atol=1e-12)
+    toff = np.concatenate([[0], np.cumsum(g["tst_lens"])])
+    segs = {str(n): g["tst_frames"][toff[i]:toff[i + 1]] for i, n in enumerate(g["ndx_segset"])}
+    sc = orc.gmm_scoring(gmm, models, M, g["ndx_modelset"], g["ndx_segset"], g["trialmask"], segs)
+    np.testing.assert_allclose(sc, g["scores"], rtol=1e-9, atol=1e-11)

@@ -275,8 +275,51 @@ def gen_stats_and_tv(sidekit, tmp):
           " |iv - iv_single| =", np.abs(tv["iv"] - tv["iv_single"]).max())
 
 
+def gen_gmm_scoring(sidekit):
+    """MAP adaptation (statserver.py:986-1028) + GMM-UBM log-likelihood-ratio scoring (gmm_scoring.py:56-119)."""
+    C, D = 16, 10
+    g = orc.random_gmm(C, D, seed=41)
+    ubm = make_ubm(sidekit, g.w, g.mu, g.invcov)
+    rs = np.random.RandomState(42)
+    enr_lens = [int(x) for x in rs.randint(60, 200, size=7)]
+    enr_spk = ["spkA", "spkB", "spkC", "spkA", "spkB", "spkC", "spkA"]
+    tst_lens = [int(x) for x in rs.randint(30, 150, size=5)]
+    table = {}
+    for i, L in enumerate(enr_lens):
+        table["e%03d" % i] = orc.synth_frames(L, dim=D, clusters=4, seed=200 + 7 * (ord(enr_spk[i][-1]) - 65), dtype=np.float64) \
+            + 0.3 * np.random.RandomState(300 + i).randn(L, D)
+    for i, L in enumerate(tst_lens):
+        table["t%03d" % i] = orc.synth_frames(L, dim=D, clusters=4, seed=200 + 7 * (i % 3), dtype=np.float64) \
+            + 0.3 * np.random.RandomState(400 + i).randn(L, D)
+    fs = mem_server(sidekit, table)
+    idmap = sidekit.IdMap()
+    idmap.leftids = np.array(enr_spk)
+    idmap.rightids = np.array(["e%03d" % i for i in range(len(enr_lens))])
+    idmap.start = np.empty(len(enr_lens), "|O")
+    idmap.stop = np.empty(len(enr_lens), "|O")
+    ss = sidekit.StatServer(idmap, ubm=ubm)
+    ss.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(len(enr_lens)), num_thread=1)
+    enroll = ss.adapt_mean_map_multisession(ubm, r=16)
+    ndx = sidekit.Ndx()
+    ndx.modelset = np.array(["spkA", "spkB", "spkC"])
+    ndx.segset = np.array(["t%03d" % i for i in range(len(tst_lens))])
+    ndx.trialmask = np.array([[1, 1, 0, 1, 1], [1, 0, 1, 1, 0], [0, 1, 1, 1, 1]], dtype=bool)
+    scores = np.zeros(ndx.trialmask.shape)
+    sys.modules["sidekit.gmm_scoring"].gmm_scoring_singleThread(ubm, enroll, ndx, fs, scores)
+    out = dict(w=ubm.w, mu=ubm.mu, invcov=ubm.invcov, enr_lens=np.array(enr_lens), enr_spk=np.array(enr_spk),
+               enr_frames=np.vstack([table["e%03d" % i] for i in range(len(enr_lens))]),
+               tst_lens=np.array(tst_lens), tst_frames=np.vstack([table["t%03d" % i] for i in range(len(tst_lens))]),
+               enroll_modelset=np.array(enroll.modelset), enroll_stat1=enroll.stat1.copy(),
+               ndx_modelset=ndx.modelset, ndx_segset=ndx.segset, trialmask=ndx.trialmask, scores=scores)
+    np.savez_compressed(os.path.join(OUT, "gmm_scoring.npz"), **out)
+    print("gmm_scoring", scores)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "scoring":
+        gen_gmm_scoring(import_reference())
+        return
     sidekit = import_reference()
     print("reference sidekit", getattr(sidekit, "__version__", "?"), "STAT_TYPE", sidekit.STAT_TYPE)
     gen_estep(sidekit, "c8_d6", C=8, D=6, T=300, seed=3)
@@ -286,6 +329,7 @@ def main():
     gen_em_uniform(sidekit)
     with tempfile.TemporaryDirectory() as tmp:
         gen_stats_and_tv(sidekit, tmp)
+    gen_gmm_scoring(sidekit)
 
 
 if __name__ == "__main__":
