@@ -101,6 +101,13 @@ int skm_bw_stats(void *ctx, const float *X_dev, long T, const int64_t *seg_off_d
                  const void *packed_dev, double *stat0_dev, double *stat1_dev,
                  void *ws_dev, size_t ws_bytes, void *stream);
 
+/* Mean of v over each segment [seg_off[s], seg_off[s+1]) (seg_off: S+1 int64, dev), float64 sums:
+ * out_dev[s] = mean(v[seg_off[s] : seg_off[s+1]]); an empty segment gives NaN (numpy's mean of nothing).
+ * With v = skm_gmm_loglik's output this is the per-segment mean frame log-likelihood `log_lk.mean()` of
+ * gmm_scoring_singleThread (sidekit/gmm_scoring.py:105-107 and :114-116). */
+int skm_segment_mean(void *ctx, const float *v_dev, const int64_t *seg_off_dev, int S, double *out_dev,
+                     void *stream);
+
 /* Column sums of X and X^2 over T frames: out_dev = [ sum x (D) | sum x^2 (D) ] float64.
  * Replaces the two reductions of Mixture._init (sidekit/mixture.py:631-632).
  * ws_dev needs skm_moments_workspace_bytes(ctx, D) bytes. */

@@ -2959,3 +2959,35 @@ extern "C" int skm_moments(void *ctx_, const float *X, long T, int D, double *ou
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// per-segment mean of a float32 vector in float64 (gmm_scoring: mean frame log-likelihood of a test
+// segment, sidekit/gmm_scoring.py:107,116).  One workgroup per segment, fixed summation order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_segment_mean(const float *__restrict__ v, const int64_t *__restrict__ seg_off,
+                                                      double *__restrict__ out)
+{
+    __shared__ double part[4];
+    const long a = seg_off[blockIdx.x], b = seg_off[blockIdx.x + 1];
+    double s = 0.0;
+    for (long t = a + threadIdx.x; t < b; t += 256) s += (double)v[t];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = (part[0] + part[1]) + (part[2] + part[3]);
+        out[blockIdx.x] = tot / (double)(b - a);   // empty segment: 0/0 = NaN, numpy's mean of nothing
+    }
+}
+
+extern "C" int skm_segment_mean(void *ctx_, const float *v, const int64_t *seg_off, int S, double *out, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && S >= 0 && (S == 0 || (seg_off && out)), "skm_segment_mean: NULL argument");
+    if (S == 0) return SKM_OK;
+    SkmProfScope ps(ctx, "k_segment_mean", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_segment_mean, dim3(S), dim3(256), 0, (hipStream_t)stream, v, seg_off, out);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}

@@ -39,6 +39,7 @@ SIGNATURES = {
                                  _c_void_p, _c_size_t, _c_void_p]),
     "skm_bw_stats": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
                               _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "skm_segment_mean": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "skm_gemm": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_long,
                           _c_long, _c_long, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int, _c_long,
                           _c_long, _c_long, _c_void_p]),
@@ -231,6 +232,19 @@ class HipEngine(object):
                                           C, D, _c_void_p(gmm.packed.data_ptr()), _c_void_p(stat0.data_ptr()),
                                           _c_void_p(stat1.data_ptr()), _c_void_p(ws), need, self._stream()))
         return stat0, stat1
+
+    def segment_mean(self, v, seg_off):
+        """float64 mean of the float32 device vector v over each [seg_off[s], seg_off[s+1])."""
+        torch = self.torch
+        if not isinstance(seg_off, torch.Tensor):
+            seg_off = torch.as_tensor(np.asarray(seg_off, dtype=np.int64))
+        seg_off = seg_off.to(device=self.device, dtype=torch.int64).contiguous()
+        S = seg_off.numel() - 1
+        assert v.dtype == torch.float32 and v.is_contiguous()
+        out = torch.empty(S, dtype=torch.float64, device=self.device)
+        self._check(self.lib.skm_segment_mean(self.ctx, _c_void_p(v.data_ptr()), _c_void_p(seg_off.data_ptr()), S,
+                                              _c_void_p(out.data_ptr()), self._stream()))
+        return out
 
     def moments(self, X):
         """[sum x | sum x^2] over the rows of X, float64 device tensor of 2*D."""

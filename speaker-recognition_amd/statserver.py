@@ -269,5 +269,67 @@ class StatServer(object):
         self.stat1 = self.stat1 / np.sqrt(sigma.astype(STAT_TYPE))
 
 
+    # ------------------------------------------------------------------ MAP adaptation (feeds gmm_scoring)
+    # C*D element-wise float64 updates on already-reduced statistics: host, like the GMM M-step.
+    def get_model_stat0(self, mod_id):
+        return self.stat0[self.modelset == mod_id, :]
+
+    def get_model_stat1(self, mod_id):
+        return self.stat1[self.modelset == mod_id, :]
+
+    def sum_stat_per_model(self):
+        """Statistics summed over the sessions of every unique model (statserver.py:1206-1226)."""
+        out = StatServer(engine=self._engine)
+        out.modelset = np.unique(self.modelset)
+        out.segset = out.modelset
+        out.stat0 = np.zeros((out.modelset.shape[0], self.stat0.shape[1]), dtype=STAT_TYPE)
+        out.stat1 = np.zeros((out.modelset.shape[0], self.stat1.shape[1]), dtype=STAT_TYPE)
+        out.start = np.empty(out.segset.shape, '|O')
+        out.stop = np.empty(out.segset.shape, '|O')
+        session_per_model = np.zeros(out.modelset.shape[0])
+        for idx, model in enumerate(out.modelset):
+            sel = self.modelset == model
+            out.stat0[idx, :] = self.stat0[sel, :].sum(axis=0)
+            out.stat1[idx, :] = self.stat1[sel, :].sum(axis=0)
+            session_per_model[idx] += sel.sum()
+        return out, session_per_model
+
+    def _map_means(self, ubm, stat0, stat1, alpha, norm):
+        index_map = np.repeat(np.arange(ubm.distrib_nb()), ubm.dim())
+        with np.errstate(divide="ignore", invalid="ignore"):
+            M = stat1 / stat0[:, index_map]
+        M[np.isnan(M)] = 0  # empty components keep the UBM mean
+        M = alpha[:, index_map] * M + (1 - alpha[:, index_map]) * np.tile(ubm.get_mean_super_vector(), (M.shape[0], 1))
+        if norm:
+            # Kullback-Leibler normalisation, diagonal covariance (statserver.py:974-980)
+            M = M * np.sqrt(np.repeat(ubm.w, ubm.dim()) * ubm.get_invcov_super_vector())
+        return M.astype(dtype=STAT_TYPE)
+
+    def adapt_mean_map(self, ubm, r=16, norm=False):
+        """One MAP-adapted mean super-vector per session (statserver.py:946-984)."""
+        out = StatServer(engine=self._engine)
+        out.modelset, out.segset, out.start, out.stop = self.modelset, self.segset, self.start, self.stop
+        out.stat0 = np.ones((self.segset.shape[0], 1), dtype=STAT_TYPE)
+        eps = np.finfo(np.float32).eps
+        alpha = (self.stat0 + eps) / (self.stat0 + eps + r)
+        out.stat1 = self._map_means(ubm, self.stat0, self.stat1, alpha, norm)
+        return out
+
+    def adapt_mean_map_multisession(self, ubm, r=16, norm=False):
+        """One MAP-adapted mean super-vector per unique model, statistics summed over its sessions
+        (statserver.py:986-1028)."""
+        models = np.unique(self.modelset)
+        out = StatServer(engine=self._engine)
+        out.modelset = models
+        out.segset = np.unique(self.modelset)
+        out.start = np.empty(models.shape, dtype="|O")
+        out.stop = np.empty(models.shape, dtype="|O")
+        out.stat0 = np.ones((models.shape[0], 1), dtype=STAT_TYPE)
+        per_model = self.sum_stat_per_model()[0]
+        alpha = per_model.stat0 / (per_model.stat0 + r)
+        out.stat1 = self._map_means(ubm, per_model.stat0, per_model.stat1, alpha, norm)
+        return out
+
+
 def _looks_like_idmap(obj):
     return all(hasattr(obj, k) for k in ("leftids", "rightids", "start", "stop"))

@@ -49,6 +49,15 @@ class OracleEngine(object):
         s0, s1 = orc.accumulate_stat(gmm.gmm, [x[off[i]:off[i + 1]] for i in range(len(off) - 1)])
         return torch.from_numpy(s0), torch.from_numpy(s1)
 
+    def loglik(self, X, gmm):
+        lp = orc.log_posterior(gmm.gmm, X.numpy().astype(np.float64))
+        return torch.from_numpy(orc.logsumexp_rows(lp)[1].astype(np.float32))
+
+    def segment_mean(self, v, seg_off):
+        off = np.asarray(seg_off)
+        x = v.numpy().astype(np.float64)
+        return torch.from_numpy(np.array([x[off[i]:off[i + 1]].mean() for i in range(len(off) - 1)]))
+
     def to_host(self, t):
         return t.detach().cpu().numpy()
 

@@ -94,9 +94,50 @@ def _worker(rank, world, port, tmp, q):
         fa.F = gt["F_it3_pool"].copy()
         ivs = fa.extract_ivectors(ut, stat_file, batch_size=7)
         out["iv"] = np.abs(ivs.stat1 - gt["iv"]).max() / np.abs(gt["iv"]).max()
+        # ---- MAP adaptation + GMM-UBM scoring: test segments sharded, score matrix summed back
+        out["sc"], out["map"] = _scoring_case(sk, eng)
         q.put((rank, out))
     finally:
         td.destroy_process_group()
+
+
+def _scoring_case(sk, eng):
+    """adapt_mean_map_multisession + gmm_scoring of the drop-in against the reference's golden scores."""
+    g = np.load(os.path.join(GOLDEN, "gmm_scoring.npz"))
+    ubm = sk.Mixture(engine=eng)
+    ubm.w, ubm.mu, ubm.invcov = g["w"].copy(), g["mu"].copy(), g["invcov"].copy()
+    ubm.cov_var_ctl = 1.0 / ubm.invcov
+    ubm._compute_all()
+    off = np.concatenate([[0], np.cumsum(g["enr_lens"])])
+    names = ["e%03d" % i for i in range(len(g["enr_lens"]))]
+    feats = {n: g["enr_frames"][off[i]:off[i + 1]] for i, n in enumerate(names)}
+    toff = np.concatenate([[0], np.cumsum(g["tst_lens"])])
+    feats.update({str(n): g["tst_frames"][toff[i]:toff[i + 1]] for i, n in enumerate(g["ndx_segset"])})
+    fs = sk.FeaturesServer(features=feats)
+    ss = sk.StatServer(sk.IdMap().set([str(x) for x in g["enr_spk"]], names), ubm=ubm, engine=eng)
+    ss.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(len(names)))
+    enroll = ss.adapt_mean_map_multisession(ubm, r=16)
+    assert list(enroll.modelset) == [str(x) for x in g["enroll_modelset"]]
+    e_map = np.abs(enroll.stat1 - g["enroll_stat1"]).max() / np.abs(g["enroll_stat1"]).max()
+    ndx = sk.Ndx()
+    ndx.modelset = np.array([str(x) for x in g["ndx_modelset"]])
+    ndx.segset = np.array([str(x) for x in g["ndx_segset"]])
+    ndx.trialmask = g["trialmask"].astype(bool)
+    sc = sk.gmm_scoring(ubm, enroll, ndx, fs, num_thread=1)
+    assert sc.validate() and (sc.scoremask == ndx.trialmask).all()
+    assert (sc.scoremat[~ndx.trialmask] == 0).all()
+    return np.abs(sc.scoremat - g["scores"]).max(), e_map
+
+
+def test_gmm_scoring_host_logic_single_process():
+    """Trial selection, masking and MAP adaptation of the drop-in (oracle-backed engine, no GPU)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import sidekit_amd as sk
+    from fake_engine import OracleEngine
+    e_sc, e_map = _scoring_case(sk, OracleEngine())
+    # frames pass through float32 on upload and the fake log-likelihood is rounded to float32
+    assert e_map < 1e-6 and e_sc < 1e-4, (e_sc, e_map)
 
 
 @pytest.mark.timeout(300)
@@ -119,6 +160,7 @@ def test_world2_gloo_matches_single_process(tmp_path):
         assert r["emu_llk"] < 1e-5, r
         assert r["bw0"] < 1e-5 and r["bw1"] < 1e-5, r
         assert r["tv_F"] < 1e-5 and r["iv"] < 1e-5, r
+        assert r["sc"] < 1e-4 and r["map"] < 1e-6, r
     # both ranks hold the same model
     assert abs(res[0]["em_mu"] - res[1]["em_mu"]) < 1e-12
 

@@ -365,3 +365,82 @@ def test_full_size_invariants_cfg3_cfg4_shape(eng):
     sess_sum = X[:L].double().sum(0).cpu().numpy()
     got = s1[0].cpu().numpy().reshape(C, D).sum(0)
     assert np.abs(got - sess_sum).max() < 1e-4 * np.abs(sess_sum).max() + 1e-3
+
+
+# ------------------------------------------------------------------ next row: MAP adaptation + GMM-UBM scoring
+def _ubm_from(sk, w, mu, invcov):
+    ubm = sk.Mixture()
+    ubm.w, ubm.mu, ubm.invcov = np.array(w, dtype="d"), np.array(mu, dtype="d"), np.array(invcov, dtype="d")
+    ubm.cov_var_ctl = 1.0 / ubm.invcov
+    ubm._compute_all()
+    return ubm
+
+
+def test_segment_mean(eng):
+    import torch
+    rs = np.random.RandomState(3)
+    v = rs.randn(5000).astype(np.float32) * 50 - 70
+    off = np.array([0, 1, 1, 300, 1301, 5000], dtype=np.int64)       # a 1-frame and an empty segment
+    got = eng.to_host(eng.segment_mean(torch.from_numpy(v).to(eng.device), off))
+    ref = np.array([v[off[i]:off[i + 1]].astype(np.float64).mean() if off[i + 1] > off[i] else np.nan
+                    for i in range(len(off) - 1)])
+    assert np.isnan(got[1])
+    m = ~np.isnan(ref)
+    np.testing.assert_allclose(got[m], ref[m], rtol=1e-13)
+
+
+def test_gmm_scoring_dropin_vs_reference_golden(sk):
+    """adapt_mean_map_multisession (statserver.py:986-1028) + gmm_scoring (gmm_scoring.py:56-185) against the
+    scores of the real reference.  Scores are differences of mean frame log-likelihoods (|llk| ~ 20): float32
+    logits bound the absolute error, 2e-4 absolute on scores of magnitude 0.1-3."""
+    g = golden("gmm_scoring.npz")
+    ubm = _ubm_from(sk, g["w"], g["mu"], g["invcov"])
+    off = np.concatenate([[0], np.cumsum(g["enr_lens"])])
+    names = ["e%03d" % i for i in range(len(g["enr_lens"]))]
+    feats = {n: g["enr_frames"][off[i]:off[i + 1]] for i, n in enumerate(names)}
+    toff = np.concatenate([[0], np.cumsum(g["tst_lens"])])
+    feats.update({str(n): g["tst_frames"][toff[i]:toff[i + 1]] for i, n in enumerate(g["ndx_segset"])})
+    fs = sk.FeaturesServer(features=feats)
+    ss = sk.StatServer(sk.IdMap().set([str(x) for x in g["enr_spk"]], names), ubm=ubm)
+    ss.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(len(names)))
+    enroll = ss.adapt_mean_map_multisession(ubm, r=16)
+    assert list(enroll.modelset) == [str(x) for x in g["enroll_modelset"]]
+    assert rel(enroll.stat1, g["enroll_stat1"]) < TOL
+    ndx = sk.Ndx()
+    ndx.modelset = np.array([str(x) for x in g["ndx_modelset"]])
+    ndx.segset = np.array([str(x) for x in g["ndx_segset"]])
+    ndx.trialmask = g["trialmask"].astype(bool)
+    sc = sk.gmm_scoring(ubm, enroll, ndx, fs)
+    assert sc.validate()
+    assert (sc.scoremat[~ndx.trialmask] == 0).all()
+    assert np.abs(sc.scoremat - g["scores"]).max() < 2e-4, np.abs(sc.scoremat - g["scores"]).max()
+
+
+def test_gmm_scoring_vs_oracle_c512(sk):
+    """Headline-shaped UBM (C=512, D=60), models absent from the enrolment and segments absent from the server
+    are dropped as the reference's ndx.filter does."""
+    C, D = 512, 60
+    gmm = orc.random_gmm(C, D, seed=5)
+    ubm = _ubm_from(sk, gmm.w, gmm.mu, gmm.invcov)
+    rs = np.random.RandomState(6)
+    models = np.array(["m%02d" % i for i in range(6)])
+    means = gmm.mu.reshape(1, -1) + 0.05 * rs.randn(5, C * D)           # m05 is not enrolled
+    enroll = sk.StatServer()
+    enroll.modelset = models[:5].copy()
+    enroll.segset = models[:5].copy()
+    enroll.start = np.empty(5, "|O")
+    enroll.stop = np.empty(5, "|O")
+    enroll.stat0 = np.ones((5, 1))
+    enroll.stat1 = means
+    segs = np.array(["t%02d" % i for i in range(7)])
+    lens = [257, 31, 1000, 1, 640, 333, 90]
+    feats = {s: orc.synth_frames(L, dim=D, seed=50 + i) for i, (s, L) in enumerate(zip(segs[:6], lens))}  # t06 missing
+    ndx = sk.Ndx()
+    ndx.modelset, ndx.segset = models, segs
+    ndx.trialmask = rs.rand(6, 7) < 0.7
+    sc = sk.gmm_scoring(ubm, enroll, ndx, sk.FeaturesServer(features=feats))
+    assert list(sc.modelset) == list(models[:5]) and list(sc.segset) == list(segs[:6])
+    ref = orc.gmm_scoring(gmm, list(models[:5]), means, sc.modelset, sc.segset, sc.scoremask,
+                          {s: np.asarray(f, dtype=np.float64) for s, f in feats.items()})
+    assert np.abs(sc.scoremat - ref).max() < 2e-4, np.abs(sc.scoremat - ref).max()
+    assert (sc.scoremat[~sc.scoremask] == 0).all()
