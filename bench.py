@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--tv-sessions", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (BW stats)")
+    ap.add_argument("--legs", default="bw,em2048,tv", help="secondary legs to run at N=1 (comma list of bw, em2048, tv)")
     args = ap.parse_args()
 
     import torch
@@ -130,6 +131,7 @@ def main():
     import sidekit_amd as sk
     eng = sk.default_engine()
     C, D, T = args.comps, args.dim, args.frames
+    legs = set() if args.no_extra else set(x for x in args.legs.split(",") if x)
 
     X = synth_frames_device(torch, T, D, seed=1234 + rank, device=dev)
     ubm = random_ubm(sk, C, D)
@@ -214,7 +216,7 @@ def main():
                                    "frac": achp / PEAK_F32_MFMA_TFLOPS, "algorithmic_flop_per_step": flop_path,
                                    "issued_mfma_flop_per_step": issued}
 
-    if rank == 0 and world == 1 and not args.no_extra:
+    if rank == 0 and world == 1 and "bw" in legs:
         # ---- Baum-Welch N/F accumulation (BASELINE configs[3], fewer sessions): C=2048, 2000-frame sessions
         Cb, S, L = 2048, min(5000, T // 2000), 2000
         ubm_b = random_ubm(sk, Cb, D, seed=11)
@@ -245,7 +247,7 @@ def main():
                               "path_frac_of_mfma_peak": 6.0 * D * Cb * S * L / dtb / 1e12 / PEAK_F32_MFMA_TFLOPS}
         del s0, s1
 
-    if rank == 0 and world == 1 and not args.no_extra:
+    if rank == 0 and world == 1 and "em2048" in legs:
         # ---- EM iteration at the target size (BASELINE configs[2] per-GPU shape, fewer frames): C=2048
         Ce, Te = 2048, min(T, 4_000_000)
         ubm_e = random_ubm(sk, Ce, D, seed=11)
@@ -271,7 +273,7 @@ def main():
                                                 "frac": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
         del ubm_e, acc_e, Xe
 
-    if rank == 0 and world == 1 and not args.no_extra:
+    if rank == 0 and world == 1 and "tv" in legs:
         # ---- TV training iteration + i-vector extraction (BASELINE configs[4], fewer sessions): R=400, C=2048
         del X
         torch.cuda.empty_cache()

@@ -38,6 +38,12 @@ struct GemmArgs {
     // contiguous and 16-byte aligned.
     const int *colmap;
     int colmap_vec;
+    // k-range trimming for triangular operands whose zero part is physically stored as zeros (the result is
+    // the same with ktrim = 0, only slower):
+    //   1: B[k][n] = 0 for k > n (B upper triangular, not transposed)    -> k < n0 + BN
+    //   2: op(A)[m][k] = 0 for k < m and op(B)[k][n] = 0 for k < n        -> k >= max(m0, n0)   (X X' with X upper)
+    //   4: op(B)[k][n] = 0 for k < n                                        -> k >= n0
+    int ktrim;
 };
 
 static inline GemmArgs skm_gemm_args(const void *A, const void *B, void *C, int M, int N, int K, long lda,

@@ -156,16 +156,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
                 if (ACC64) acc64[mi][ni][r] = 0.0;
             }
 
-    const int nk = (K + BK - 1) / BK;
+    // k range of this tile: all of K unless a triangular operand makes part of it an exact zero (ktrim)
+    int k_begin = 0, k_end = K;
+    if (g.ktrim & 1) k_end = (n0 + BN < K) ? (n0 + BN) : K;
+    if (g.ktrim & 2) k_begin = (m0 > n0) ? m0 : n0;
+    if (g.ktrim & 4) k_begin = n0;
+    if (k_begin > k_end) k_begin = k_end;
+    const int kt0 = k_begin / BK, nk = (k_end + BK - 1) / BK;
     const int lm = lane % TM, lk = lane / TM;
-    IO::load(ra, A, g.lda, akfast, avec, m0, 0, Mr, K, tid);
-    IO::load(rb, B, g.ldb, bkfast, bvec, n0, 0, N, K, tid, g.colmap);
+    IO::load(ra, A, g.lda, akfast, avec, m0, kt0 * BK, Mr, K, tid);
+    IO::load(rb, B, g.ldb, bkfast, bvec, n0, kt0 * BK, N, K, tid, g.colmap);
     IO::store(ra, As[0], LDT, akfast, tid);
     IO::store(rb, Bs[0], LDT, bkfast, tid);
     __syncthreads();
     int since = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
         if (kt + 1 < nk) {
             IO::load(ra, A, g.lda, akfast, avec, m0, (kt + 1) * BK, Mr, K, tid);
             IO::load(rb, B, g.ldb, bkfast, bvec, n0, (kt + 1) * BK, N, K, tid, g.colmap);

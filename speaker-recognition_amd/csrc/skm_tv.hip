@@ -94,51 +94,53 @@ __global__ __launch_bounds__(256) void k_cvt_f64_f32(const double *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// diagonal block of the blocked Cholesky: U = chol_upper(M_kk) (n <= 32), then W = U^-1 written back in
-// place (upper triangular, strictly lower part zeroed).  One wave per matrix, block in LDS.
+// diagonal block of the blocked Cholesky: U = chol_upper(M_kk) (n <= 64), then W = U^-1 written back in
+// place (upper triangular, strictly lower part zeroed).  One workgroup of 4 waves per matrix, block in LDS:
+// the upper triangle of `a` holds U, its strictly lower triangle receives W transposed (W[l][c] at a[c][l]).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_chol_diag(double *__restrict__ Mb, long stride, int ld, int n, int add_identity)
+#define CH_BLK 64
+__global__ __launch_bounds__(256) void k_chol_diag(double *__restrict__ Mb, long stride, int ld, int n, int add_identity)
 {
-    __shared__ double a[TV_BLK][TV_BLK + 1];
-    __shared__ double x[TV_BLK][TV_BLK + 1];
+    __shared__ double a[CH_BLK][CH_BLK + 1];
+    __shared__ double dinv[CH_BLK];
     double *M = Mb + (long)blockIdx.x * stride;
     const int t = threadIdx.x;
-    for (int e = t; e < TV_BLK * TV_BLK; e += 64) {
-        const int r = e / TV_BLK, c = e % TV_BLK;
+    for (int e = t; e < CH_BLK * CH_BLK; e += 256) {
+        const int r = e / CH_BLK, c = e % CH_BLK;
         double v = 0.0;
         if (r < n && c < n && c >= r) v = M[(long)r * ld + c];
         if (add_identity && r == c && r < n) v += 1.0;
         a[r][c] = v;
-        x[r][c] = 0.0;
     }
     __syncthreads();
-    // right-looking upper Cholesky: row j is scaled, then the trailing upper block is updated
+    // right-looking upper Cholesky: row j is scaled (a[j][j] keeps the pivot itself, 1/root goes to dinv),
+    // then the trailing upper block is updated; thread (rr, cc) owns rows j+1+rr, j+5+rr, .. of column cc
+    const int cc = t & 63, rr = t >> 6;
     for (int j = 0; j < n; ++j) {
         const double d = sqrt(a[j][j]);
-        __syncthreads();
-        if (t == j) a[j][j] = d;
         if (t > j && t < n) a[j][t] /= d;
+        if (t == j) dinv[j] = 1.0 / d;
         __syncthreads();
-        for (int e = t; e < TV_BLK * TV_BLK; e += 64) {
-            const int r = e / TV_BLK, c = e % TV_BLK;
-            if (r > j && c >= r && c < n) a[r][c] -= a[j][r] * a[j][c];
+        if (cc > j && cc < n) {
+            const double ujc = a[j][cc];
+            for (int r = j + 1 + rr; r <= cc; r += 4) a[r][cc] -= a[j][r] * ujc;
         }
         __syncthreads();
     }
-    // X = U^-1, one column per thread (back substitution)
-    if (t < n) {
-        const int c = t;
-        x[c][c] = 1.0 / a[c][c];
-        for (int i = c - 1; i >= 0; --i) {
-            double s = 0.0;
-            for (int l = i + 1; l <= c; ++l) s += a[i][l] * x[l][c];
-            x[i][c] = -s / a[i][i];
-        }
+    // W = U^-1 by rows, bottom-up: W[i][c] = -(sum_{l=i+1..c} U[i][l] W[l][c]) / U[i][i]; 4 lanes share a column
+    const int c = t >> 2, q = t & 3;
+    for (int i = n - 2; i >= 0; --i) {
+        double sacc = 0.0;
+        if (c > i && c < n)
+            for (int l = i + 1 + q; l <= c; l += 4) sacc += a[i][l] * (l == c ? dinv[c] : a[c][l]);
+        sacc += __shfl_xor(sacc, 1);
+        sacc += __shfl_xor(sacc, 2);
+        if (q == 0 && c > i && c < n) a[c][i] = -sacc * dinv[i];
+        __syncthreads();
     }
-    __syncthreads();
-    for (int e = t; e < TV_BLK * TV_BLK; e += 64) {
-        const int r = e / TV_BLK, c = e % TV_BLK;
-        if (r < n && c < n) M[(long)r * ld + c] = x[r][c];
+    for (int e = t; e < CH_BLK * CH_BLK; e += 256) {
+        const int r = e / CH_BLK, cl = e % CH_BLK;
+        if (r < n && cl < n) M[(long)r * ld + cl] = (cl > r) ? a[cl][r] : (cl == r ? dinv[r] : 0.0);
     }
 }
 
@@ -242,18 +244,18 @@ __global__ __launch_bounds__(256) void k_tv_finish_tri(const double *__restrict_
 // In-place inverse of `nb` SPD matrices (upper part valid, everything else of the buffer ZERO):
 //   Mb  [nb][R][R] f64, destroyed (ends as X = U^-1)
 //   out [nb][R][R] f64 = M^-1 (upper 64-tiles only when upper_only)
-//   Tb  [nb][32][R] f64 scratch
+//   Tb  [nb][CH_BLK][R] f64 scratch
 static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int nb, int R, int add_identity,
                            int upper_only, hipStream_t st)
 {
     const long RR = (long)R * R;
-    const int Kb = (R + TV_BLK - 1) / TV_BLK;
+    const int Kb = (R + CH_BLK - 1) / CH_BLK;
     int rc;
     for (int k = 0; k < Kb; ++k) {
-        const int r0 = k * TV_BLK, bs = (R - r0 < TV_BLK) ? (R - r0) : TV_BLK, rem = R - r0 - bs;
+        const int r0 = k * CH_BLK, bs = (R - r0 < CH_BLK) ? (R - r0) : CH_BLK, rem = R - r0 - bs;
         {
             SkmProfScope ps(ctx, "k_chol_diag", st);
-            hipLaunchKernelGGL(k_chol_diag, dim3(nb), dim3(64), 0, st, Mb + (long)r0 * R + r0, RR, R, bs, add_identity);
+            hipLaunchKernelGGL(k_chol_diag, dim3(nb), dim3(256), 0, st, Mb + (long)r0 * R + r0, RR, R, bs, add_identity);
         }
         SKM_HIP(hipGetLastError());
         if (rem <= 0) continue;
@@ -274,15 +276,16 @@ static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int
     }
     // X = U^-1 in place, block rows bottom-up (diagonal blocks already hold W_i = U_ii^-1)
     for (int i = Kb - 2; i >= 0; --i) {
-        const int r0 = i * TV_BLK, bs = TV_BLK, c0 = r0 + bs, rem = R - c0;
+        const int r0 = i * CH_BLK, bs = CH_BLK, c0 = r0 + bs, rem = R - c0;
         GemmArgs t = skm_gemm_args(Mb + (long)r0 * R + c0, Mb + (long)c0 * R + c0, Tb, bs, rem, rem, R, R, R);
         t.sA = t.sB = RR;
-        t.sC = (long)TV_BLK * R;
+        t.sC = (long)CH_BLK * R;
+        t.ktrim = 1;        // X[c0:, c0:] is upper triangular
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, t, nb, st, "k_gemm_trinv_a"))) return rc;
         GemmArgs x = skm_gemm_args(Mb + (long)r0 * R + r0, Tb, Mb + (long)r0 * R + c0, bs, rem, bs, R, R, R);
         x.alpha = -1.0;
         x.sA = x.sC = RR;
-        x.sB = (long)TV_BLK * R;
+        x.sB = (long)CH_BLK * R;
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, x, nb, st, "k_gemm_trinv_b"))) return rc;
     }
     if (!out) return SKM_OK;   // the caller works with X = U^-1 itself
@@ -290,6 +293,7 @@ static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int
     GemmArgs p = skm_gemm_args(Mb, Mb, out, R, R, R, R, R, R);
     p.transB = 1;
     p.tile_mask = upper_only ? 1 : 0;
+    p.ktrim = 2;            // X upper triangular: (X X')[i][j] sums k >= max(i, j)
     p.sA = p.sB = p.sC = RR;
     return skm_gemm_launch(ctx, SKM_GEMM_F64_F64, p, nb, st, "k_gemm_xxt");
 }
@@ -320,7 +324,7 @@ static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0)
     w.off_e = off;
     off += skm_align_up((size_t)batch * RR * sizeof(float), 256);
     w.off_tb = off;
-    off += skm_align_up((size_t)batch * TV_BLK * R * sizeof(double), 256);
+    off += skm_align_up((size_t)batch * CH_BLK * R * sizeof(double), 256);
     w.off_aux = off;
     off += skm_align_up((size_t)S * R * sizeof(double), 256);
     w.off_eh32 = off;
@@ -497,12 +501,14 @@ extern "C" int skm_tv_mstep(void *ctx_, double *A_aug, const double *Cacc, int C
         double *Y = Linv;   // [nb][D][R]
         GemmArgs g = skm_gemm_args(Cacc + (long)c0 * D, A_aug + c0 * RR, Y, D, R, R, CD, R, R);
         g.transA = 1;       // Y[d][r] = sum_k C[k][cD+d] X[k][r]
+        g.ktrim = 1;        // X[k][r] = 0 for k > r
         g.sA = D;
         g.sB = RR;
         g.sC = (long)D * R;
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, g, nb, st, "k_gemm_mstep"))) return rc;
         GemmArgs t = skm_gemm_args(Y, A_aug + c0 * RR, F_out + (long)c0 * D * R, D, R, R, R, R, R);
         t.transB = 1;       // T_c[d][r] = sum_j Y[d][j] X[r][j]
+        t.ktrim = 4;        // X[r][j] = 0 for j < r
         t.sA = (long)D * R;
         t.sB = RR;
         t.sC = (long)D * R;
