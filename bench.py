@@ -111,7 +111,8 @@ def main():
     ap.add_argument("--tv-sessions", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (BW stats)")
-    ap.add_argument("--legs", default="bw,em2048,tv", help="secondary legs to run at N=1 (comma list of bw, em2048, tv)")
+    ap.add_argument("--legs", default="bw,em2048,scoring,tv",
+                    help="secondary legs to run at N=1 (comma list of bw, em2048, scoring, tv)")
     args = ap.parse_args()
 
     import torch
@@ -272,6 +273,38 @@ def main():
                                                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                                 "frac": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
         del ubm_e, acc_e, Xe
+
+    if rank == 0 and world == 1 and "scoring" in legs:
+        # ---- GMM-UBM LLR scoring (next row after the statistics path, gmm_scoring.py:56-119): every enrolled model
+        # against every test segment = one log-likelihood pass per model over all test frames + segment means
+        Cs, n_models, n_seg, Ls = 2048, 16, min(500, T // 2000), 2000
+        ubm_s = random_ubm(sk, Cs, D, seed=11)
+        Xs = X[:n_seg * Ls]
+        seg = torch.arange(0, n_seg + 1, dtype=torch.int64, device=dev) * Ls
+        rs = np.random.RandomState(5)
+        packs = [eng.pack(ubm_s.w, ubm_s.mu + 0.05 * rs.randn(Cs, D), ubm_s.invcov) for _ in range(n_models)]
+        p_ubm = eng.pack(ubm_s.w, ubm_s.mu, ubm_s.invcov)
+
+        def score_all():
+            base = eng.segment_mean(eng.loglik(Xs, p_ubm), seg)
+            return torch.stack([eng.segment_mean(eng.loglik(Xs, p), seg) - base for p in packs])
+        score_all()
+        torch.cuda.synchronize()
+        eng.profile(True)
+        t0 = time.perf_counter()
+        score_all()
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
+        prof = eng.profile_read()
+        eng.profile(False)
+        fl = 4.0 * D * Cs * n_seg * Ls * (n_models + 1)       # the two GEMMs of compute_log_posterior_probabilities
+        result["scoring"] = {"value": n_models * n_seg / dts, "unit": "trials/s",
+                             "model_frames_per_s": (n_models + 1) * n_seg * Ls / dts,
+                             "workload": "gmm_scoring body, C=%d, %d models x %d segments x %d frames"
+                                         % (Cs, n_models, n_seg, Ls),
+                             "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof.items())},
+                             "path_frac_of_mfma_peak": fl / dts / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        del Xs, packs
 
     if rank == 0 and world == 1 and "tv" in legs:
         # ---- TV training iteration + i-vector extraction (BASELINE configs[4], fewer sessions): R=400, C=2048

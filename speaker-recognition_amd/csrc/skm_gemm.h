@@ -44,6 +44,10 @@ struct GemmArgs {
     //   2: op(A)[m][k] = 0 for k < m and op(B)[k][n] = 0 for k < n        -> k >= max(m0, n0)   (X X' with X upper)
     //   4: op(B)[k][n] = 0 for k < n                                        -> k >= n0
     int ktrim;
+    // XCD-aware tile order: 0 = plain 2-D grid; 1 = the M tiles of one N tile column run back to back on one XCD
+    // (they share the B tile in that XCD's L2); 2 = the N tiles of one M tile row do (they share the A tile).
+    int swz;
+    int swz_tiles_m, swz_tiles_n;  // set by skm_gemm_launch
 };
 
 static inline GemmArgs skm_gemm_args(const void *A, const void *B, void *C, int M, int N, int K, long lda,

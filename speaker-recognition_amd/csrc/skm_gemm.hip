@@ -124,7 +124,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int z = blockIdx.z;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (g.swz) {
+        // XCD-aware tile order (1-D launch): workgroups w and w + 8 share an XCD and its L2.  Groups of 8 "slow"
+        // tile indices (one per XCD) x all "fast" tile indices: the workgroups that an XCD runs back to back
+        // walk the fast dimension and re-use the slow dimension's operand tile from that XCD's L2.
+        const int fast = g.swz == 1 ? g.swz_tiles_m : g.swz_tiles_n;
+        const int grp = bx / (8 * fast), r = bx % (8 * fast);
+        const int slow_idx = grp * 8 + (r & 7), fast_idx = r >> 3;
+        by = g.swz == 1 ? fast_idx : slow_idx;
+        bx = g.swz == 1 ? slow_idx : fast_idx;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
 
     const TI *A = static_cast<const TI *>(g.A) + (long)z * g.sA;
     const TI *B = static_cast<const TI *>(g.B) + (long)z * g.sB;
@@ -247,11 +258,21 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
                 g.M, g.N, g.K, batch);
     const int tile = (kind == SKM_GEMM_F32_F32 || kind == SKM_GEMM_F32_F64ACC || kind == SKM_GEMM_F32_F64OUT) ? 128 : 64;
     const int ncols = g.tri_n > 0 ? g.tri_n : g.N;
-    const dim3 grid((ncols + tile - 1) / tile, (g.M + tile - 1) / tile, batch);
+    dim3 grid((ncols + tile - 1) / tile, (g.M + tile - 1) / tile, batch);
     SKM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm(%s): grid too large", tag);
+    int swz_tm = 0, swz_tn = 0;
+    if (g.swz) {
+        SKM_REQUIRE(g.tri_n == 0 && (g.swz == 1 || g.swz == 2), "gemm(%s): bad swizzle", tag);
+        swz_tm = (int)grid.y;
+        swz_tn = (int)grid.x;
+        const int fast = g.swz == 1 ? swz_tm : swz_tn, slow = g.swz == 1 ? swz_tn : swz_tm;
+        grid = dim3((unsigned)((slow + 7) / 8 * 8 * fast), 1, batch);
+    }
     SKM_REQUIRE(!g.colmap || (!g.transB && g.tile_mask == 0 && g.tri_n == 0), "gemm(%s): colmap needs plain B", tag);
     const size_t esz = (kind == SKM_GEMM_F64_F64 || kind == SKM_GEMM_F64_F32OUT) ? 8 : 4;
     GemmArgs gv = g;
+    gv.swz_tiles_m = swz_tm;
+    gv.swz_tiles_n = swz_tn;
     gv.vec = (vec_ok(g.A, g.lda, g.sA, 0, 0, esz) ? 1 : 0) |
              (vec_ok(g.B, g.ldb, g.sB, g.tri_ldz, g.tri_n > 0 && g.tri_blk % (16 / (int)esz) == 0, esz) ? 2 : 0);
     if (g.tri_n > 0 && g.tri_blk % (16 / (int)esz) != 0) gv.vec &= 1;

@@ -427,12 +427,14 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         g.sA = kc;
         g.sB = kc * R;
         g.sC = S * R;
+        g.swz = 2;          // the R/128 column tiles share the f~ row tile
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, g, w.ksplit, st, "k_gemm_aux"))) return rc;
         SkmProfScope ps(ctx, "k_sum_slabs", st);
         hipLaunchKernelGGL(k_sum_slabs, dim3(ctx->cu_count * 2), dim3(256), 0, st, aux, slabs, S * R, w.ksplit);
         SKM_HIP(hipGetLastError());
     } else {
         GemmArgs g = skm_gemm_args(ftilde, T32, aux, (int)S, R, (int)CD, CD, R, R);
+        g.swz = 2;
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, g, 1, st, "k_gemm_aux"))) return rc;
     }
     for (long b0 = 0; b0 < S; b0 += batch) {
@@ -442,6 +444,7 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         GemmArgs l = skm_gemm_args(naug + b0 * ldn, G, Mb, nb, NT, C, ldn, RR, RR);
         l.colmap = cmap;
         l.colmap_vec = (R % 4 == 0);
+        l.swz = 1;          // the session tiles of one G column tile share it in one XCD's L2
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, l, 1, st, "k_gemm_lbuild"))) return rc;
         if ((rc = blocked_inverse(ctx, Mb, train ? Linv : nullptr, Tb, nb, R, 1, 1, st))) return rc;
         if (!train) {
@@ -462,6 +465,7 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
             a.beta = 1.0;
             a.colmap = cmap;
             a.colmap_vec = (R % 4 == 0);
+            a.swz = 1;      // the component tiles of one e_hh column tile share it
             if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, a, 1, st, "k_gemm_aacc"))) return rc;
         }
     }
@@ -470,6 +474,7 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         GemmArgs c = skm_gemm_args(eh32, ftilde, Cacc, R, (int)CD, (int)S, R, CD, CD);
         c.transA = 1;
         c.beta = 1.0;
+        c.swz = 1;          // the R/128 row tiles share the f~ column tile
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, c, 1, st, "k_gemm_cacc"))) return rc;
     }
     return SKM_OK;
