@@ -89,7 +89,7 @@ def cpu_baseline(C, D, seconds_target=15.0):
     t0 = time.perf_counter()
     orc.expectation(gmm, chunk[:10000])
     probe = time.perf_counter() - t0
-    n_chunks = int(max(1, min(40, seconds_target / max(probe * 5.0, 1e-3))))
+    n_chunks = int(max(1, min(80, seconds_target / max(probe * 5.0, 1e-3))))
     t0 = time.perf_counter()
     N, F, S, llk = orc.expectation_chunked(gmm, [chunk] * n_chunks)
     orc.maximization(gmm, N, F, S)
@@ -144,18 +144,23 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, reps):
+        """barrier + synchronize on both sides of `reps` calls, MAX over ranks of the wall time (seconds)."""
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            td.all_reduce(tt, op=td.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, r
+
     for _ in range(args.warmup):
         em_iteration(ubm, accum, X)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        llk = em_iteration(ubm, accum, X)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, llk = timed(lambda: em_iteration(ubm, accum, X), args.steps)
     ms_per_step = 1e3 * dt / args.steps
     value = world * T * args.steps / dt
 
@@ -170,15 +175,16 @@ def main():
                    "final_mean_llk": float(llk)},
     }
 
+    # ---- per-kernel timing with HIP events on the launch stream (separate, un-timed pass).  Every rank runs
+    # it (the iteration contains the all-reduce); rank 0 reports its own kernels.
+    eng.profile(True)
+    nprof = 3
+    for _ in range(nprof):
+        em_iteration(ubm, accum, X)
+    torch.cuda.synchronize()
+    prof = eng.profile_read()
+    eng.profile(False)
     if rank == 0:
-        # ---- per-kernel timing with HIP events on the launch stream (separate, un-timed pass)
-        eng.profile(True)
-        nprof = 3
-        for _ in range(nprof):
-            em_iteration(ubm, accum, X)
-        torch.cuda.synchronize()
-        prof = eng.profile_read()
-        eng.profile(False)
         kt = {k: v[1] / v[0] for k, v in prof.items()}            # avg ms per launch
         flop_path = 8.0 * D * C * T         # log-lik GEMM + statistics GEMM
         single = [k for k in ("k_estep_fat", "k_estep_fused") if k in kt]
@@ -217,8 +223,11 @@ def main():
                                    "frac": achp / PEAK_F32_MFMA_TFLOPS, "algorithmic_flop_per_step": flop_path,
                                    "issued_mfma_flop_per_step": issued}
 
-    if rank == 0 and world == 1 and "bw" in legs:
-        # ---- Baum-Welch N/F accumulation (BASELINE configs[3], fewer sessions): C=2048, 2000-frame sessions
+    # The secondary legs run on EVERY rank (weak scaling: each rank owns its sessions / frames); values are
+    # whole-job aggregates over the MAX-over-ranks wall time, kernel tables are rank 0's.
+    if "bw" in legs:
+        # ---- Baum-Welch N/F accumulation (BASELINE configs[3], fewer sessions): C=2048, 2000-frame sessions.
+        # No data-path collective: every session row has one owner.
         Cb, S, L = 2048, min(5000, T // 2000), 2000
         ubm_b = random_ubm(sk, Cb, D, seed=11)
         packed = eng.pack(ubm_b.w, ubm_b.mu, ubm_b.invcov)
@@ -227,56 +236,52 @@ def main():
         s0 = torch.empty((S, Cb), dtype=torch.float64, device=dev)
         s1 = torch.empty((S, Cb * D), dtype=torch.float64, device=dev)
         eng.bw_stats(Xb, seg, packed, s0, s1)
-        torch.cuda.synchronize()
         eng.profile(True)
-        t0 = time.perf_counter()
-        for _ in range(2):
-            eng.bw_stats(Xb, seg, packed, s0, s1)
-        torch.cuda.synchronize()
-        dtb = (time.perf_counter() - t0) / 2
+        dtb, _ = timed(lambda: eng.bw_stats(Xb, seg, packed, s0, s1), 2)
+        dtb /= 2
         prof = eng.profile_read()
         eng.profile(False)
         k_bw = "k_bw_team" if "k_bw_team" in prof else "k_stats_bw"
         t_bw = prof[k_bw][1] / prof[k_bw][0]
-        result["bw_stats"] = {"value": S * L / dtb, "unit": "frames/s",
-                              "workload": "accumulate_stat body, C=%d, %d sessions x %d frames" % (Cb, S, L),
+        fl_bw = (6.0 if k_bw == "k_bw_team" else 2.0) * D * Cb * S * L
+        result["bw_stats"] = {"value": world * S * L / dtb, "unit": "frames/s", "n_gpus": world,
+                              "workload": "accumulate_stat body, C=%d, %d sessions x %d frames per GPU" % (Cb, S, L),
                               "roofline": {"bound": "mfma", "kernel": k_bw,
-                                           "achieved": (6.0 if k_bw == "k_bw_team" else 2.0) * D * Cb * S * L / (t_bw * 1e-3) / 1e12,
+                                           "achieved": fl_bw / (t_bw * 1e-3) / 1e12,
                                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": (6.0 if k_bw == "k_bw_team" else 2.0) * D * Cb * S * L / (t_bw * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                           "frac": fl_bw / (t_bw * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                            "avg_launch_ms": t_bw},
                               "path_frac_of_mfma_peak": 6.0 * D * Cb * S * L / dtb / 1e12 / PEAK_F32_MFMA_TFLOPS}
         del s0, s1
 
-    if rank == 0 and world == 1 and "em2048" in legs:
+    if "em2048" in legs:
         # ---- EM iteration at the target size (BASELINE configs[2] per-GPU shape, fewer frames): C=2048
         Ce, Te = 2048, min(T, 4_000_000)
         ubm_e = random_ubm(sk, Ce, D, seed=11)
         acc_e = copy.deepcopy(ubm_e)
         Xe = X[:Te]
         em_iteration(ubm_e, acc_e, Xe)
-        torch.cuda.synchronize()
         eng.profile(True)
-        t0 = time.perf_counter()
-        for _ in range(2):
-            em_iteration(ubm_e, acc_e, Xe)
-        torch.cuda.synchronize()
-        dte = (time.perf_counter() - t0) / 2
+        dte, _ = timed(lambda: em_iteration(ubm_e, acc_e, Xe), 2)
+        dte /= 2
         prof = eng.profile_read()
         eng.profile(False)
         kte = {k: v[1] / v[0] for k, v in prof.items()}
         t_k = sum(kte.values())
-        result["em_c2048"] = {"value": Te / dte, "unit": "frames/s", "ms_per_iteration": 1e3 * dte,
-                              "workload": "UBM EM iteration, C=%d, D=%d, %d frames" % (Ce, D, Te),
+        result["em_c2048"] = {"value": world * Te / dte, "unit": "frames/s", "n_gpus": world,
+                              "ms_per_iteration": 1e3 * dte,
+                              "workload": "UBM EM iteration (E-step + all-reduce + M-step), C=%d, D=%d, %d frames per GPU"
+                                          % (Ce, D, Te),
                               "kernels_ms": {k: round(v, 3) for k, v in kte.items()},
                               "roofline_path": {"bound": "mfma", "achieved": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12,
                                                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                                 "frac": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
         del ubm_e, acc_e, Xe
 
-    if rank == 0 and world == 1 and "scoring" in legs:
+    if "scoring" in legs:
         # ---- GMM-UBM LLR scoring (next row after the statistics path, gmm_scoring.py:56-119): every enrolled model
-        # against every test segment = one log-likelihood pass per model over all test frames + segment means
+        # against every test segment = one log-likelihood pass per model over all test frames + segment means.
+        # Test segments are sharded over ranks, no collective.
         Cs, n_models, n_seg, Ls = 2048, 16, min(500, T // 2000), 2000
         ubm_s = random_ubm(sk, Cs, D, seed=11)
         Xs = X[:n_seg * Ls]
@@ -289,31 +294,29 @@ def main():
             base = eng.segment_mean(eng.loglik(Xs, p_ubm), seg)
             return torch.stack([eng.segment_mean(eng.loglik(Xs, p), seg) - base for p in packs])
         score_all()
-        torch.cuda.synchronize()
         eng.profile(True)
-        t0 = time.perf_counter()
-        score_all()
-        torch.cuda.synchronize()
-        dts = time.perf_counter() - t0
+        dts, _ = timed(score_all, 1)
         prof = eng.profile_read()
         eng.profile(False)
         fl = 4.0 * D * Cs * n_seg * Ls * (n_models + 1)       # the two GEMMs of compute_log_posterior_probabilities
-        result["scoring"] = {"value": n_models * n_seg / dts, "unit": "trials/s",
-                             "model_frames_per_s": (n_models + 1) * n_seg * Ls / dts,
-                             "workload": "gmm_scoring body, C=%d, %d models x %d segments x %d frames"
+        result["scoring"] = {"value": world * n_models * n_seg / dts, "unit": "trials/s", "n_gpus": world,
+                             "model_frames_per_s": world * (n_models + 1) * n_seg * Ls / dts,
+                             "workload": "gmm_scoring body, C=%d, %d models x %d segments x %d frames per GPU"
                                          % (Cs, n_models, n_seg, Ls),
                              "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof.items())},
                              "path_frac_of_mfma_peak": fl / dts / 1e12 / PEAK_F32_MFMA_TFLOPS}
         del Xs, packs
 
-    if rank == 0 and world == 1 and "tv" in legs:
-        # ---- TV training iteration + i-vector extraction (BASELINE configs[4], fewer sessions): R=400, C=2048
+    if "tv" in legs:
+        # ---- TV training iteration + i-vector extraction (BASELINE configs[4], fewer sessions): R=400, C=2048.
+        # Sessions are sharded (each rank owns --tv-sessions of them); training reduce-scatters the accumulators
+        # over components, solves its C/N components and all-gathers the new rows (factor_analyser._tv_iteration).
         del X
         torch.cuda.empty_cache()
         Ct, R, St = 2048, 400, args.tv_sessions
         ubm_t = random_ubm(sk, Ct, D, seed=11)
         gen = torch.Generator(device=dev)
-        gen.manual_seed(4321)
+        gen.manual_seed(4321 + rank)
         post = torch.softmax(2.0 * torch.randn(St, Ct, generator=gen, device=dev), dim=1)
         stat0 = (2000.0 * post).to(torch.float32)
         mu_sv = torch.as_tensor(ubm_t.get_mean_super_vector(), device=dev)
@@ -325,36 +328,31 @@ def main():
         ft, naug = eng.tv_whiten(stat0, stat1, ubm_t.get_mean_super_vector(), ubm_t.get_invcov_super_vector())
         del stat1
         fa = sk.FactorAnalyser()
-        T_dev = torch.as_tensor(0.1 * np.random.RandomState(7).randn(Ct * D, R), device=dev)
-        T_dev = fa._tv_iteration(ft, naug, T_dev, Ct, D, R, St, True, 1024)      # warm-up iteration
-        torch.cuda.synchronize()
+        tv_state = {"T": torch.as_tensor(0.1 * np.random.RandomState(7).randn(Ct * D, R), device=dev)}
+
+        def tv_iter():
+            tv_state["T"] = fa._tv_iteration(ft, naug, tv_state["T"], Ct, D, R, world * St, True, 1024)
+        tv_iter()                                                               # warm-up iteration
         eng.profile(True)
-        t0 = time.perf_counter()
-        T_dev = fa._tv_iteration(ft, naug, T_dev, Ct, D, R, St, True, 1024)
-        torch.cuda.synchronize()
-        dt_tv = time.perf_counter() - t0
+        dt_tv, _ = timed(tv_iter, 1)
         prof_tv = eng.profile_read()
-        T32, G = eng.tv_prepare(T_dev, Ct, D)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        e_h, _ = eng.tv_estep(naug, ft, T32, G, Ct, D, batch=1024, uncertainty=True)
-        torch.cuda.synchronize()
-        dt_iv = time.perf_counter() - t0
+        T32, G = eng.tv_prepare(tv_state["T"], Ct, D)
+        dt_iv, _ = timed(lambda: eng.tv_estep(naug, ft, T32, G, Ct, D, batch=1024, uncertainty=True), 1)
         prof_iv = eng.profile_read()
         eng.profile(False)
         flop_train, flop_iv = 9.18e8, 4.5e8          # algorithmic flop per session
         result["tv"] = {
             "workload": "TV EM iteration (E-step + M-step + min-div) and extract_ivectors, R=%d, C=%d, D=%d, "
-                        "%d synthetic sessions" % (R, Ct, D, St),
-            "train_sessions_per_s": St / dt_tv, "train_s_per_iteration": dt_tv,
-            "train_algorithmic_tflops": flop_train * St / dt_tv / 1e12,
-            "ivectors_per_s": St / dt_iv,
-            "extract_algorithmic_tflops": flop_iv * St / dt_iv / 1e12,
+                        "%d synthetic sessions per GPU" % (R, Ct, D, St), "n_gpus": world,
+            "train_sessions_per_s": world * St / dt_tv, "train_s_per_iteration": dt_tv,
+            "train_algorithmic_tflops": flop_train * world * St / dt_tv / 1e12,
+            "ivectors_per_s": world * St / dt_iv,
+            "extract_algorithmic_tflops": flop_iv * world * St / dt_iv / 1e12,
             "train_kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof_tv.items())},
             "extract_kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof_iv.items())},
-            "note": "M-step cost (2048 R x R inverses) is independent of the session count and is amortised "
-                    "over 50k sessions in configs[4]; it is included in train_s_per_iteration here"}
-        del ft, naug, T32, G, e_h, T_dev
+            "note": "M-step cost (R x R inverses of the rank's C/N components) is independent of the session count "
+                    "and is amortised over 50k sessions in configs[4]; it is included in train_s_per_iteration here"}
+        del ft, naug, T32, G
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(C, D)
