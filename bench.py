@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--comps", type=int, default=512)
     ap.add_argument("--dim", type=int, default=60)
     ap.add_argument("--tv-sessions", type=int, default=4096)
+    ap.add_argument("--tv-batch", type=int, default=2048, help="sessions per TV E-step batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (BW stats)")
     ap.add_argument("--legs", default="bw,em2048,scoring,tv",
@@ -331,13 +332,13 @@ def main():
         tv_state = {"T": torch.as_tensor(0.1 * np.random.RandomState(7).randn(Ct * D, R), device=dev)}
 
         def tv_iter():
-            tv_state["T"] = fa._tv_iteration(ft, naug, tv_state["T"], Ct, D, R, world * St, True, 1024)
+            tv_state["T"] = fa._tv_iteration(ft, naug, tv_state["T"], Ct, D, R, world * St, True, args.tv_batch)
         tv_iter()                                                               # warm-up iteration
         eng.profile(True)
         dt_tv, _ = timed(tv_iter, 1)
         prof_tv = eng.profile_read()
         T32, G = eng.tv_prepare(tv_state["T"], Ct, D)
-        dt_iv, _ = timed(lambda: eng.tv_estep(naug, ft, T32, G, Ct, D, batch=1024, uncertainty=True), 1)
+        dt_iv, _ = timed(lambda: eng.tv_estep(naug, ft, T32, G, Ct, D, batch=args.tv_batch, uncertainty=True), 1)
         prof_iv = eng.profile_read()
         eng.profile(False)
         flop_train, flop_iv = 9.18e8, 4.5e8          # algorithmic flop per session

@@ -175,18 +175,51 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
     if (k_begin > k_end) k_begin = k_end;
     const int kt0 = k_begin / BK, nk = (k_end + BK - 1) / BK;
     const int lm = lane % TM, lk = lane / TM;
-    IO::load(ra, A, g.lda, akfast, avec, m0, kt0 * BK, Mr, K, tid);
-    IO::load(rb, B, g.ldb, bkfast, bvec, n0, kt0 * BK, N, K, tid, g.colmap);
+
+    // Interior tiles (all rows and columns inside the matrix, 16-byte loads legal) take a loader without any
+    // bounds test: one 32-bit element offset per vector, fixed for the whole k loop, on top of a wave-uniform
+    // base pointer that advances by one k-tile per iteration.  Edge tiles and a ragged last k-tile take the
+    // general loader.
+    const bool interior = avec && bvec && m0 + BM <= Mr && n0 + BN <= N;
+    unsigned offa[IO::NV], offb[IO::NV];
+#pragma unroll
+    for (int i = 0; i < IO::NV; ++i) {
+        int row, k;
+        IO::coord(tid, i, akfast, row, k);
+        offa[i] = akfast ? (unsigned)((long)row * g.lda + k) : (unsigned)((long)k * g.lda + row);
+        IO::coord(tid, i, bkfast, row, k);
+        if (bkfast) offb[i] = (unsigned)((long)row * g.ldb + k);
+        else offb[i] = (unsigned)((long)k * g.ldb) + (unsigned)((g.colmap && interior) ? g.colmap[n0 + row] - g.colmap[n0] : row);
+    }
+    const TI *At = akfast ? (A + (long)m0 * g.lda) : (A + m0);                                  // tile origin at k = 0
+    const TI *Bt = bkfast ? (B + (long)n0 * g.ldb) : (B + ((g.colmap && interior) ? g.colmap[n0] : n0));
+    const long inca = akfast ? 1 : g.lda, incb = bkfast ? 1 : g.ldb;                          // elements per unit of k
+    auto load_tile = [&](int kt) {
+        if (interior && (kt + 1) * BK <= K) {
+            const TI *ap = At + (long)kt * BK * inca, *bp = Bt + (long)kt * BK * incb;
+#pragma unroll
+            for (int i = 0; i < IO::NV; ++i) {
+                const typename IO::vec_t va = *reinterpret_cast<const typename IO::vec_t *>(ap + offa[i]);
+                const typename IO::vec_t vb = *reinterpret_cast<const typename IO::vec_t *>(bp + offb[i]);
+#pragma unroll
+                for (int j = 0; j < IO::VW; ++j) {
+                    ra[i * IO::VW + j] = va[j];
+                    rb[i * IO::VW + j] = vb[j];
+                }
+            }
+        } else {
+            IO::load(ra, A, g.lda, akfast, avec, m0, kt * BK, Mr, K, tid);
+            IO::load(rb, B, g.ldb, bkfast, bvec, n0, kt * BK, N, K, tid, g.colmap);
+        }
+    };
+    load_tile(kt0);
     IO::store(ra, As[0], LDT, akfast, tid);
     IO::store(rb, Bs[0], LDT, bkfast, tid);
     __syncthreads();
     int since = 0;
     for (int kt = kt0; kt < nk; ++kt) {
         const int cur = (kt - kt0) & 1;
-        if (kt + 1 < nk) {
-            IO::load(ra, A, g.lda, akfast, avec, m0, (kt + 1) * BK, Mr, K, tid);
-            IO::load(rb, B, g.ldb, bkfast, bvec, n0, (kt + 1) * BK, N, K, tid, g.colmap);
-        }
+        if (kt + 1 < nk) load_tile(kt + 1);
         const TI *Ac = As[cur] + wm * 2 * TM + lm;
         const TI *Bc = Bs[cur] + wn * 2 * TM + lm;
 #pragma unroll

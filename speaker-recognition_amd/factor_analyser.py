@@ -197,7 +197,7 @@ class FactorAnalyser(object):
             ft, naug, total = resident
         else:
             ft, naug, total, _ = self._resident_stats(sources, ubm)
-        batch = 1024   # device batch: results do not depend on it (the reference batches only to bound host memory)
+        batch = 2048   # device batch: results do not depend on it (the reference batches only to bound host memory)
         T_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(self.F, dtype=np.float64))).to(eng.device)
         for it in range(nb_iter):
             T_dev = self._tv_iteration(ft, naug, T_dev, C, D, tv_rank, total, min_div, batch)
