@@ -2282,12 +2282,24 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const double *__restrict__
     const int cb = (comp >> 5) / NCT;
     const int cl = comp - cb * NCT * 32;
     const long slab_elems = (long)NCT * 32 * NFW;
-    double sum = 0.0;
-    for (int fs = 0; fs < n_fs; ++fs)
-        for (int w = 0; w < NW; ++w) {
-            const long slot = ((long)fs * n_cb + cb) * NW + w;
-            sum += slabs[slot * slab_elems + (long)cl * NFW + col];
+    // slot (fs, w) of this component block lives at ((fs * n_cb + cb) * NW + w); 8 partial sums keep 8 loads in
+    // flight, always combined in the same order (bit-identical runs)
+    const double *src = slabs + (long)cl * NFW + col;
+    const int n_slots = n_fs * NW;
+    double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int i = 0;
+    for (; i + 8 <= n_slots; i += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = i + u, fs = q / NW, w = q - fs * NW;
+            part[u] += src[(((long)fs * n_cb + cb) * NW + w) * slab_elems];
         }
+    }
+    for (; i < n_slots; ++i) {
+        const int fs = i / NW, w = i - fs * NW;
+        part[i & 7] += src[(((long)fs * n_cb + cb) * NW + w) * slab_elems];
+    }
+    const double sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     *dst = accumulate ? (*dst + sum) : sum;
 }
 
@@ -2429,9 +2441,12 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
     p->tg.tail = g.tail;
     p->tg.vec4 = (D % 4 == 0) ? 1 : 0;
     // sweep 1: largest component block / wave count that fits the LDS
+    // (a model of one or two component tiles -- the first stages of EM_split -- takes a block of that size
+    // instead of padding tiles)
     p->nct1 = 0;
+    const int nct_max = g.CT >= 3 ? 4 : g.CT;
     for (int nw = 8; nw >= 1 && !p->nct1; nw >>= 1)
-        for (int nct = 4; nct >= 1; nct >>= 1)
+        for (int nct = nct_max; nct >= 1; nct >>= 1)
             if (lds_bytes(nct, nw, g) <= SKM_LDS_BUDGET) {
                 p->nct1 = nct;
                 p->nw1 = nw;
@@ -2440,6 +2455,7 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
     // sweep 2: component tiles per wave limited by the accumulator registers (NCT*NF*16 <= 128..160)
     p->nf2 = g.NJT * (with_s ? 2 : 1);
     p->nct2 = (p->nf2 <= 4) ? 2 : 1;
+    if (with_s && g.CT == 1 && g.NJT <= 2) p->nct2 = 1;
     p->nw2 = 0;
     for (int nw = 8; nw >= 1; nw >>= 1)
         if (lds_bytes(p->nct2, nw, g) <= SKM_LDS_BUDGET) {
@@ -2592,11 +2608,15 @@ static int launch_lse(SkmCtx *ctx, const Plan &p, const float *X, long T, const 
     return SKM_OK;
 }
 
-template <int NJT, bool WITH_S, bool BW>
+template <int NJT, bool WITH_S, bool BW, int NCT_ = 0>
 static int launch_stats_t(SkmCtx *ctx, const Plan &p, const StatsArgs &a, hipStream_t st)
 {
     constexpr int NF = NJT * (WITH_S ? 2 : 1);
-    constexpr int NCT = (NF <= 4) ? 2 : 1;
+    constexpr int NCT = NCT_ ? NCT_ : ((NF <= 4) ? 2 : 1);
+    if (p.nct2 != NCT) {
+        skm_set_error("statistics sweep: plan wants %d component tiles per wave, kernel has %d", p.nct2, NCT);
+        return SKM_ERR_UNSUPPORTED;
+    }
     int rc = set_lds(k_stats<NJT, NCT, WITH_S, BW>, p.lds2);
     if (rc) return rc;
     SkmProfScope ps(ctx, BW ? "k_stats_bw" : "k_stats_em", st);
@@ -2608,6 +2628,9 @@ static int launch_stats_t(SkmCtx *ctx, const Plan &p, const StatsArgs &a, hipStr
 template <bool WITH_S, bool BW>
 static int launch_stats(SkmCtx *ctx, const Plan &p, const StatsArgs &a, hipStream_t st)
 {
+    // a single component tile (C <= 32, the first stages of EM_split): one tile per wave instead of a padding tile
+    if (WITH_S && !BW && p.nct2 == 1 && p.g.NJT == 1) return launch_stats_t<1, WITH_S, BW, 1>(ctx, p, a, st);
+    if (WITH_S && !BW && p.nct2 == 1 && p.g.NJT == 2) return launch_stats_t<2, WITH_S, BW, 1>(ctx, p, a, st);
     switch (p.g.NJT) {
     case 1: return launch_stats_t<1, WITH_S, BW>(ctx, p, a, st);
     case 2: return launch_stats_t<2, WITH_S, BW>(ctx, p, a, st);
