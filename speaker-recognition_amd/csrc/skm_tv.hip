@@ -238,6 +238,70 @@ __global__ __launch_bounds__(256) void k_tv_finish_tri(const double *__restrict_
     }
 }
 
+// Extraction without uncertainty: e_h = L^-1 aux from the blocked Cholesky factor alone (two triangular solves,
+// R^2 work per session) -- neither U^-1 nor L^-1 is formed.  After the factorisation the block row k of the buffer
+// holds W_k = U_kk^-1 on the diagonal block (upper, strictly lower part zero) and U[k, j > k] to its right.
+//   forward   U' y = aux :  y_k = W_k' (aux_k - sum_{i < k} U[i, k]' y_i)
+//   backward  U  x = y   :  x_k = W_k  (y_k   - sum_{j > k} U[k, j]  x_j)
+// One workgroup (4 waves) per session, y / x in LDS.
+__global__ __launch_bounds__(256) void k_tv_solve(const double *__restrict__ Ub, int R, const double *__restrict__ aux,
+                                                  double *__restrict__ e_h, float *__restrict__ e_h32)
+{
+    extern __shared__ double sh[];          // y[R] (overwritten by x), t[CH_BLK], part[4][CH_BLK]
+    double *y = sh, *tv = sh + R, *part = sh + R + CH_BLK;
+    const long b = blockIdx.x;
+    const double *U = Ub + b * (long)R * R;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int Kb = (R + CH_BLK - 1) / CH_BLK;
+    for (int i = t; i < R; i += 256) y[i] = aux[b * R + i];
+    __syncthreads();
+    // ---- forward
+    for (int k = 0; k < Kb; ++k) {
+        const int r0 = k * CH_BLK, bs = (R - r0 < CH_BLK) ? (R - r0) : CH_BLK;
+        // column sums over the rows above the block: lane = column, wave = row phase (coalesced along the row)
+        double s = 0.0;
+        if (lane < bs)
+            for (int i = wave; i < r0; i += 4) s += U[(long)i * R + r0 + lane] * y[i];
+        part[wave * CH_BLK + lane] = s;
+        __syncthreads();
+        if (t < bs) tv[t] = y[r0 + t] - ((part[t] + part[CH_BLK + t]) + (part[2 * CH_BLK + t] + part[3 * CH_BLK + t]));
+        __syncthreads();
+        // y_k = W_k' t : y[c] = sum_{i <= c} W[i][c] t[i]
+        s = 0.0;
+        if (lane < bs)
+            for (int i = wave; i <= lane; i += 4) s += U[(long)(r0 + i) * R + r0 + lane] * tv[i];
+        part[wave * CH_BLK + lane] = s;
+        __syncthreads();
+        if (t < bs) y[r0 + t] = (part[t] + part[CH_BLK + t]) + (part[2 * CH_BLK + t] + part[3 * CH_BLK + t]);
+        __syncthreads();
+    }
+    // ---- backward: rows of the block are dealt to the waves, lanes stride along the row (coalesced), shuffle reduce
+    for (int k = Kb - 1; k >= 0; --k) {
+        const int r0 = k * CH_BLK, bs = (R - r0 < CH_BLK) ? (R - r0) : CH_BLK, c0 = r0 + bs;
+        for (int r = wave; r < bs; r += 4) {
+            double s = 0.0;
+            for (int j = c0 + lane; j < R; j += 64) s += U[(long)(r0 + r) * R + j] * y[j];
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+            if (lane == 0) tv[r] = y[r0 + r] - s;
+        }
+        __syncthreads();
+        // x_k = W_k s : x[r] = sum_{c >= r} W[r][c] s[c]
+        for (int r = wave; r < bs; r += 4) {
+            double s = (lane >= r && lane < bs) ? U[(long)(r0 + r) * R + r0 + lane] * tv[lane] : 0.0;
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+            if (lane == 0) y[r0 + r] = s;
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < R; i += 256) {
+        const double v = y[i];
+        e_h[b * R + i] = v;
+        if (e_h32) e_h32[b * R + i] = (float)v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------
@@ -246,7 +310,7 @@ __global__ __launch_bounds__(256) void k_tv_finish_tri(const double *__restrict_
 //   out [nb][R][R] f64 = M^-1 (upper 64-tiles only when upper_only)
 //   Tb  [nb][CH_BLK][R] f64 scratch
 static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int nb, int R, int add_identity,
-                           int upper_only, hipStream_t st)
+                           int upper_only, hipStream_t st, bool factor_only = false)
 {
     const long RR = (long)R * R;
     const int Kb = (R + CH_BLK - 1) / CH_BLK;
@@ -274,6 +338,7 @@ static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int
         u.sA = u.sB = u.sC = RR;
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, u, nb, st, "k_gemm_chol_update"))) return rc;
     }
+    if (factor_only) return SKM_OK;   // block rows hold [W_k | U[k, j > k]]: enough for triangular solves
     // X = U^-1 in place, block rows bottom-up (diagonal blocks already hold W_i = U_ii^-1)
     for (int i = Kb - 2; i >= 0; --i) {
         const int r0 = i * CH_BLK, bs = CH_BLK, c0 = r0 + bs, rem = R - c0;
@@ -446,8 +511,13 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         l.colmap_vec = (R % 4 == 0);
         l.swz = 1;          // the session tiles of one G column tile share it in one XCD's L2
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, l, 1, st, "k_gemm_lbuild"))) return rc;
-        if ((rc = blocked_inverse(ctx, Mb, train ? Linv : nullptr, Tb, nb, R, 1, 1, st))) return rc;
-        if (!train) {
+        const bool solve_only = !train && !iv_sigma;
+        if ((rc = blocked_inverse(ctx, Mb, train ? Linv : nullptr, Tb, nb, R, 1, 1, st, solve_only))) return rc;
+        if (solve_only) {
+            SkmProfScope ps(ctx, "k_tv_solve", st);
+            hipLaunchKernelGGL(k_tv_solve, dim3(nb), dim3(256), (R + 5 * CH_BLK) * sizeof(double), st, Mb, R,
+                               aux + b0 * R, e_h + b0 * R, eh32 + b0 * R);
+        } else if (!train) {
             SkmProfScope ps(ctx, "k_tv_finish", st);
             hipLaunchKernelGGL(k_tv_finish_tri, dim3(nb), dim3(256), 2 * R * sizeof(double), st, Mb, R, aux + b0 * R,
                                e_h + b0 * R, eh32 + b0 * R, iv_sigma ? iv_sigma + b0 * R : nullptr);

@@ -256,7 +256,8 @@ class FactorAnalyser(object):
         C, D = ubm.distrib_nb(), ubm.dim()
         T_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(self.F, dtype=np.float64))).to(eng.device)
         T32, G = eng.tv_prepare(T_dev, C, D)
-        e_h, sig = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=True)
+        # without `uncertainty` the device solves L x = aux from the Cholesky factor and never forms U^-1
+        e_h, sig = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=bool(uncertainty))
         return e_h, sig
 
     def extract_ivectors(self, ubm, stat_server_filename, prefix='', batch_size=300, uncertainty=False,
@@ -273,9 +274,10 @@ class FactorAnalyser(object):
         iv_sigma = np.zeros((nb_sessions, tv_rank), dtype=STAT_TYPE)
         a, b = local[0]
         if ft is not None:
-            e_h, sig = self._extract(ft, naug, ubm, 1024, True)
+            e_h, sig = self._extract(ft, naug, ubm, 2048, uncertainty)
             iv[a:b] = eng.to_host(e_h)
-            iv_sigma[a:b] = eng.to_host(sig)
+            if sig is not None:
+                iv_sigma[a:b] = eng.to_host(sig)
         if dist.is_dist():
             torch = eng.torch
             t = torch.from_numpy(np.concatenate([iv, iv_sigma], axis=1)).to(eng.device)
@@ -305,7 +307,7 @@ class FactorAnalyser(object):
         d1 = torch.from_numpy(np.ascontiguousarray(stat_server.stat1, dtype=np.float64)).to(eng.device)
         ft, naug = eng.tv_whiten(d0, d1, ubm.get_mean_super_vector(), ubm.get_invcov_super_vector())
         stat_server.whiten_stat1(ubm.get_mean_super_vector(), 1. / ubm.get_invcov_super_vector())
-        e_h, sig = self._extract(ft, naug, ubm, 1024, True)
+        e_h, sig = self._extract(ft, naug, ubm, 2048, uncertainty)
         iv_stat_server = StatServer()
         iv_stat_server.modelset = copy.deepcopy(stat_server.modelset)
         iv_stat_server.segset = copy.deepcopy(stat_server.segset)

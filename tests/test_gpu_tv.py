@@ -145,6 +145,16 @@ def test_estep_accumulators_and_mstep(eng, case):
     assert rel(e_h, iv) < (1e-4 if case == "r400" else 2e-5)
     assert rel(sig, iv_sigma) < (1e-4 if case == "r400" else 2e-5)
     assert min_cosine(e_h, iv) > 0.9999
+    # extraction without uncertainty takes the triangular-solve path (k_tv_solve): same i-vectors
+    ft, naug = eng.tv_whiten(dev(eng, s0), dev(eng, s1), gmm.mu.flatten(), gmm.invcov.flatten())
+    T32, G = eng.tv_prepare(dev(eng, Fm), C, D)
+    for b in (batch, 5):
+        e_s, none = eng.tv_estep(naug, ft, T32, G, C, D, batch=b, uncertainty=False)
+        assert none is None
+        e_s = eng.to_host(e_s)
+        assert rel(e_s, iv) < (1e-4 if case == "r400" else 2e-5)
+        assert rel(e_s, e_h) < (1e-5 if case == "r400" else 1e-9)
+        assert min_cosine(e_s, iv) > 0.9999
     # M-step from the DEVICE accumulators against the oracle's M-step from ITS accumulators
     Fn = eng.to_host(eng.tv_mstep(A_dev, C_dev, C, D, R))
     rF = orc.tv_mstep(rA, rC, rR / s0.shape[0], D, min_div=False)
@@ -188,6 +198,10 @@ def test_total_variability_dropin_vs_reference_golden(sk, tmp_path):
     assert min_cosine(ivs.stat1, g["iv"]) > 0.9999
     assert rel(ivs.stat1, g["iv"]) < 2e-5
     assert rel(sig, g["iv_sigma"]) < 2e-5
+    ivs_d = fa3.extract_ivectors(ubm, stat_file, batch_size=7)          # default: no uncertainty (solve path)
+    assert isinstance(ivs_d, sk.StatServer) and rel(ivs_d.stat1, g["iv"]) < 2e-5
+    ivs_s = fa3.extract_ivectors_single(ubm, sk.StatServer(stat_file))
+    assert rel(ivs_s.stat1, g["iv_single"]) < 2e-5
     ss2 = sk.StatServer(stat_file)
     ivs2, sig2 = fa3.extract_ivectors_single(ubm, ss2, uncertainty=True)
     assert min_cosine(ivs2.stat1, g["iv_single"]) > 0.9999
