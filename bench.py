@@ -307,6 +307,20 @@ def main():
                              "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof.items())},
                              "path_frac_of_mfma_peak": fl / dts / 1e12 / PEAK_F32_MFMA_TFLOPS}
         del Xs, packs
+        # cosine scoring of i-vectors (iv_scoring.py:90-99): length normalisation + enroll . test' in float64
+        ne = 8192
+        iv_e = torch.randn(ne, 400, dtype=torch.float64, device=dev)
+        iv_t = torch.randn(ne, 400, dtype=torch.float64, device=dev)
+
+        def cosine_all():
+            return eng.gemm(eng.row_normalize_(iv_e.clone()), eng.row_normalize_(iv_t.clone()), transB=True)
+        cosine_all()
+        dtc, _ = timed(cosine_all, 3)
+        dtc /= 3
+        result["scoring"]["cosine"] = {"value": world * ne * ne / dtc, "unit": "trials/s",
+                                       "workload": "cosine_scoring body, %d x %d i-vectors of rank 400 per GPU, float64" % (ne, ne),
+                                       "f64_tflops": 2.0 * ne * ne * 400 / dtc / 1e12}
+        del iv_e, iv_t
 
     if "tv" in legs:
         # ---- TV training iteration + i-vector extraction (BASELINE configs[4], fewer sessions): R=400, C=2048.

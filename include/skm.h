@@ -171,6 +171,13 @@ int skm_tv_estep(void *ctx, const float *naug_dev, const float *ftilde_dev, long
 int skm_tv_mstep(void *ctx, double *A_aug_dev, const double *Cacc_dev, int C, int D, int R, int batch,
                  double *F_out_dev, void *ws_dev, size_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------------------ i-vector back-end (next row) ---- */
+
+/* Length normalisation in place of the rows of X_dev[S*R] (float64): x / max(||x||, 1e-8).
+ * Replaces StatServer.norm_stat1 (sidekit/statserver.py:677-680) as used by cosine_scoring
+ * (sidekit/iv_scoring.py:96-98); the score matrix itself (iv_scoring.py:99) is skm_gemm with transB. */
+int skm_row_normalize(void *ctx, double *X_dev, long S, int R, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -448,3 +448,15 @@ def gmm_scoring(gmm, enroll_modelset, enroll_means, ndx_modelset, ndx_segset, tr
             mu = enroll_means[enroll_modelset.index(model)]
             scores[mi, ts] = logsumexp_rows(log_posterior(gmm, cep, mu=mu))[1].mean() - ubm_llk
     return scores
+
+
+def cosine_scoring(enroll_iv, test_iv, wccn=None):
+    """Score matrix of sidekit/iv_scoring.py:90-99: optional right-product by `wccn` (statserver.py:682-688),
+    length normalisation with the norm clipped at 1e-8 (statserver.py:677-680), enroll . test'."""
+    e = np.asarray(enroll_iv, dtype=F64)
+    t = np.asarray(test_iv, dtype=F64)
+    if wccn is not None:
+        e, t = e.dot(wccn), t.dot(wccn)
+    e = (e.T / np.clip(np.linalg.norm(e, axis=1), 1e-8, np.inf)).T
+    t = (t.T / np.clip(np.linalg.norm(t, axis=1), 1e-8, np.inf)).T
+    return e.dot(t.T)

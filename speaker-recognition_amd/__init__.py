@@ -8,6 +8,8 @@ from .mixture import Mixture  # noqa: F401
 from .statserver import StatServer  # noqa: F401
 from .factor_analyser import FactorAnalyser  # noqa: F401
 from .gmm_scoring import gmm_scoring, gmm_scoring_singleThread  # noqa: F401
+from . import iv_scoring  # noqa: F401
+from .iv_scoring import cosine_scoring  # noqa: F401
 from . import dist  # noqa: F401
 
 PARAM_TYPE = "float32"

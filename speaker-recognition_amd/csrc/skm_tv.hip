@@ -591,3 +591,33 @@ extern "C" int skm_tv_mstep(void *ctx_, double *A_aug, const double *Cacc, int C
     }
     return SKM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// i-vector back-end (next row): length normalisation of the rows of X[S][R] in place, norm clipped below at
+// 1e-8 (StatServer.norm_stat1, sidekit/statserver.py:677-680).  One wave per row, float64.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_normalize(double *__restrict__ X, long S, int R)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= S) return;
+    double *x = X + row * R;
+    double s = 0.0;
+    for (int j = lane; j < R; j += 64) s += x[j] * x[j];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+    double nrm = sqrt(s);
+    if (nrm < 1e-8) nrm = 1e-8;
+    for (int j = lane; j < R; j += 64) x[j] = x[j] / nrm;
+}
+
+extern "C" int skm_row_normalize(void *ctx_, double *X, long S, int R, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && S >= 0 && R > 0 && (S == 0 || X), "skm_row_normalize: bad argument");
+    if (S == 0) return SKM_OK;
+    SkmProfScope ps(ctx, "k_row_normalize", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_row_normalize, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X, S, R);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}

@@ -40,6 +40,7 @@ SIGNATURES = {
     "skm_bw_stats": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
                               _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "skm_segment_mean": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p]),
+    "skm_row_normalize": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
     "skm_gemm": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_long,
                           _c_long, _c_long, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int, _c_long,
                           _c_long, _c_long, _c_void_p]),
@@ -279,6 +280,13 @@ class HipEngine(object):
                                       1 if transA else 0, 1 if transB else 0, float(alpha), float(beta), 1, 0, 0, 0,
                                       self._stream()))
         return C
+
+    def row_normalize_(self, X):
+        """In-place length normalisation of the rows of a float64 device matrix (norm clipped at 1e-8)."""
+        assert X.dim() == 2 and X.dtype == self.torch.float64 and X.is_contiguous()
+        self._check(self.lib.skm_row_normalize(self.ctx, _c_void_p(X.data_ptr()), X.shape[0], X.shape[1],
+                                               self._stream()))
+        return X
 
     def tv_whiten(self, stat0, stat1, mu_sv, invcov_sv):
         """(ftilde float32 [S x CD], naug float32 [S x (C+1)]) from device statistics (float32 or float64)."""

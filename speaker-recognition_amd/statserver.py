@@ -269,6 +269,26 @@ class StatServer(object):
         self.stat1 = self.stat1 / np.sqrt(sigma.astype(STAT_TYPE))
 
 
+    def _take(self, indx):
+        self.segset = self.segset[indx]
+        self.modelset = self.modelset[indx]
+        self.start = self.start[indx]
+        self.stop = self.stop[indx]
+        self.stat0 = self.stat0[indx, :]
+        self.stat1 = self.stat1[indx, :]
+
+    def align_segments(self, segment_list):
+        """Rows re-ordered (and possibly dropped) to follow `segment_list` (statserver.py:579-592)."""
+        self._take(np.array([np.argwhere(self.segset == v)[0][0] for v in segment_list], dtype=np.int64))
+
+    def align_models(self, model_list):
+        """Rows re-ordered to follow `model_list`, first session of each model (statserver.py:594-607)."""
+        self._take(np.array([np.argwhere(self.modelset == v)[0][0] for v in model_list], dtype=np.int64))
+
+    def rotate_stat1(self, R):
+        """stat1 <- stat1 . R (statserver.py:682-688)."""
+        self.stat1 = np.dot(self.stat1, R)
+
     # ------------------------------------------------------------------ MAP adaptation (feeds gmm_scoring)
     # C*D element-wise float64 updates on already-reduced statistics: host, like the GMM M-step.
     def get_model_stat0(self, mod_id):

@@ -103,5 +103,10 @@ class OracleEngine(object):
             Fm[c * D:(c + 1) * D] = np.linalg.solve(A[c], Cc[:, c * D:(c + 1) * D]).T
         return torch.from_numpy(Fm)
 
-    def gemm(self, A, B, **kw):
-        return torch.from_numpy(A.numpy().dot(B.numpy()))
+    def gemm(self, A, B, transB=False, **kw):
+        return torch.from_numpy(A.numpy().dot(B.numpy().T if transB else B.numpy()))
+
+    def row_normalize_(self, X):
+        x = X.numpy()
+        x /= np.clip(np.linalg.norm(x, axis=1), 1e-8, np.inf)[:, None]
+        return X

@@ -221,3 +221,35 @@ def test_total_variability_dropin_vs_reference_golden(sk, tmp_path):
     np.testing.assert_allclose(ss3.stat1, orc.whiten_stat1(ss3.stat0, before, ubm.get_mean_super_vector(),
                                                            1. / ubm.get_invcov_super_vector()),
                                rtol=1e-12, atol=1e-12)
+
+
+# ------------------------------------------------------------------ next row: cosine scoring of i-vectors
+def test_cosine_scoring_dropin_vs_reference_golden(sk):
+    """cosine_scoring (iv_scoring.py:61-106) on the device (float64 GEMM + row normalisation) against the real
+    reference, including a missing model / segment, a re-ordered Ndx, a null i-vector and a WCCN rotation."""
+    from test_oracle_golden import _cosine_case
+    s, sw, g = _cosine_case(sk)
+    assert np.abs(s - g["scoremat"]).max() < 1e-12
+    assert np.abs(sw - g["scoremat_wccn"]).max() < 1e-12
+
+
+def test_cosine_scoring_large_vs_oracle(sk, eng):
+    rs = np.random.RandomState(9)
+    E, T, R = 700, 1300, 400
+
+    def server(prefix, n):
+        ss = sk.StatServer()
+        ss.modelset = np.array(["%s%04d" % (prefix, i) for i in range(n)])
+        ss.segset = ss.modelset.copy()
+        ss.start = np.empty(n, "|O")
+        ss.stop = np.empty(n, "|O")
+        ss.stat0 = np.ones((n, 1))
+        ss.stat1 = rs.randn(n, R)
+        return ss
+    enroll, test = server("m", E), server("t", T)
+    ndx = sk.Ndx()
+    ndx.modelset, ndx.segset = enroll.modelset.copy(), test.segset.copy()
+    ndx.trialmask = np.ones((E, T), dtype=bool)
+    sc = sk.cosine_scoring(enroll, test, ndx)
+    ref = orc.cosine_scoring(enroll.stat1, test.stat1)
+    assert np.abs(sc.scoremat - ref).max() < 1e-12

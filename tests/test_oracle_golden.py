@@ -159,3 +159,47 @@ def test_map_adaptation_and_gmm_scoring_vs_reference_golden():
     segs = {str(n): g["tst_frames"][toff[i]:toff[i + 1]] for i, n in enumerate(g["ndx_segset"])}
     sc = orc.gmm_scoring(gmm, models, M, g["ndx_modelset"], g["ndx_segset"], g["trialmask"], segs)
     np.testing.assert_allclose(sc, g["scores"], rtol=1e-9, atol=1e-11)
+
+
+def _cosine_case(sk, engine=None):
+    """Drop-in cosine_scoring on the golden case of the real reference; returns (scores, scores_wccn, golden)."""
+    g = golden("cosine_scoring.npz")
+
+    def server(models, segs, iv):
+        ss = sk.StatServer(engine=engine)
+        ss.modelset = np.array([str(x) for x in models])
+        ss.segset = np.array([str(x) for x in segs])
+        ss.start = np.empty(len(segs), "|O")
+        ss.stop = np.empty(len(segs), "|O")
+        ss.stat0 = np.ones((len(segs), 1))
+        ss.stat1 = np.array(iv, dtype="d")
+        return ss
+    enroll = server(g["enroll_modelset"], g["enroll_modelset"], g["enroll_iv"])
+    test = server(g["test_segset"], g["test_segset"], g["test_iv"])
+    ndx = sk.Ndx()
+    ndx.modelset = np.array([str(x) for x in g["ndx_modelset"]])
+    ndx.segset = np.array([str(x) for x in g["ndx_segset"]])
+    ndx.trialmask = g["trialmask"].astype(bool)
+    before = enroll.stat1.copy()
+    sc = sk.cosine_scoring(enroll, test, ndx, wccn=None)
+    scw = sk.cosine_scoring(enroll, test, ndx, wccn=g["wccn"])
+    assert np.array_equal(enroll.stat1, before)                        # inputs are not modified (deep copies)
+    assert list(sc.modelset) == [str(x) for x in g["out_modelset"]]
+    assert list(sc.segset) == [str(x) for x in g["out_segset"]]
+    assert np.array_equal(sc.scoremask, g["scoremask"]) and sc.validate()
+    return sc.scoremat, scw.scoremat, g
+
+
+def test_cosine_scoring_oracle_and_host_logic_vs_reference_golden():
+    """cosine_scoring (iv_scoring.py:61-106).  The oracle's arithmetic and the drop-in's model /
+    segment alignment (oracle-backed engine, no GPU) against the real reference."""
+    import sidekit_amd as sk
+    from fake_engine import OracleEngine
+    g = golden("cosine_scoring.npz")
+    e_idx = [list(g["enroll_modelset"]).index(m) for m in g["out_modelset"]]
+    t_idx = [list(g["test_segset"]).index(s) for s in g["out_segset"]]
+    close(orc.cosine_scoring(g["enroll_iv"][e_idx], g["test_iv"][t_idx]), g["scoremat"], rtol=1e-12)
+    close(orc.cosine_scoring(g["enroll_iv"][e_idx], g["test_iv"][t_idx], g["wccn"]), g["scoremat_wccn"], rtol=1e-12)
+    s, sw, g = _cosine_case(sk, OracleEngine())
+    close(s, g["scoremat"], rtol=1e-12)
+    close(sw, g["scoremat_wccn"], rtol=1e-12)

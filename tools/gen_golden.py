@@ -315,8 +315,44 @@ def gen_gmm_scoring(sidekit):
     print("gmm_scoring", scores)
 
 
+def gen_cosine(sidekit):
+    """cosine_scoring (iv_scoring.py:61-106) with and without a WCCN rotation; the Ndx names a model that was
+    never enrolled and a segment that has no i-vector, and lists them in another order than the StatServers."""
+    rs = np.random.RandomState(77)
+    R = 12
+
+    def iv_server(names_model, names_seg):
+        ss = sidekit.StatServer()
+        ss.modelset = np.array(names_model)
+        ss.segset = np.array(names_seg)
+        ss.start = np.empty(len(names_seg), "|O")
+        ss.stop = np.empty(len(names_seg), "|O")
+        ss.stat0 = np.ones((len(names_seg), 1))
+        ss.stat1 = rs.randn(len(names_seg), R) * rs.uniform(0.5, 3.0, size=(len(names_seg), 1))
+        return ss
+    enroll = iv_server(["m%d" % i for i in range(6)], ["m%d" % i for i in range(6)])
+    test = iv_server(["t%d" % i for i in range(8)], ["t%d" % i for i in range(8)])
+    test.stat1[3] = 0.0                                   # a null i-vector: the 1e-8 clip of norm_stat1
+    ndx = sidekit.Ndx()
+    ndx.modelset = np.array(["m4", "m1", "mX", "m0", "m5"])
+    ndx.segset = np.array(["t7", "t3", "tY", "t0", "t1", "t5"])
+    ndx.trialmask = rs.rand(5, 6) < 0.6
+    wccn = np.linalg.cholesky(np.cov(rs.randn(R, 200)) + 0.1 * np.eye(R))
+    sc = sidekit.iv_scoring.cosine_scoring(enroll, test, ndx, wccn=None)
+    scw = sidekit.iv_scoring.cosine_scoring(enroll, test, ndx, wccn=wccn)
+    np.savez_compressed(os.path.join(OUT, "cosine_scoring.npz"),
+                        enroll_modelset=enroll.modelset, enroll_iv=enroll.stat1, test_segset=test.segset,
+                        test_iv=test.stat1, ndx_modelset=ndx.modelset, ndx_segset=ndx.segset, trialmask=ndx.trialmask,
+                        wccn=wccn, scoremat=sc.scoremat, scoremask=sc.scoremask, out_modelset=sc.modelset,
+                        out_segset=sc.segset, scoremat_wccn=scw.scoremat)
+    print("cosine", sc.scoremat.shape, list(sc.modelset), list(sc.segset))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "cosine":
+        gen_cosine(import_reference())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "scoring":
         gen_gmm_scoring(import_reference())
         return
@@ -330,6 +366,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         gen_stats_and_tv(sidekit, tmp)
     gen_gmm_scoring(sidekit)
+    gen_cosine(sidekit)
 
 
 if __name__ == "__main__":
