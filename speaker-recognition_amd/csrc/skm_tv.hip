@@ -315,8 +315,21 @@ static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int
     const long RR = (long)R * R;
     const int Kb = (R + CH_BLK - 1) / CH_BLK;
     int rc;
+    // left-looking by block rows: row k first receives the contributions of all the rows above it in ONE product
+    // with K = 64 k (each block row is read-modify-written once, not once per earlier panel), then its diagonal
+    // block is factored and the row is scaled
     for (int k = 0; k < Kb; ++k) {
         const int r0 = k * CH_BLK, bs = (R - r0 < CH_BLK) ? (R - r0) : CH_BLK, rem = R - r0 - bs;
+        if (k > 0) {
+            // M[k, j >= k] -= U[0:r0, k]' U[0:r0, j >= k]   (rows above sit right of their own diagonal blocks)
+            GemmArgs u = skm_gemm_args(Mb + r0, Mb + r0, Mb + (long)r0 * R + r0, bs, R - r0, r0, R, R, R);
+            u.transA = 1;
+            u.alpha = -1.0;
+            u.beta = 1.0;
+            u.tile_mask = 1;
+            u.sA = u.sB = u.sC = RR;
+            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, u, nb, st, "k_gemm_chol_update"))) return rc;
+        }
         {
             SkmProfScope ps(ctx, "k_chol_diag", st);
             hipLaunchKernelGGL(k_chol_diag, dim3(nb), dim3(256), 0, st, Mb + (long)r0 * R + r0, RR, R, bs, add_identity);
@@ -329,14 +342,6 @@ static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int
         g.transA = 1;
         g.sA = g.sB = g.sC = RR;
         if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, g, nb, st, "k_gemm_chol_panel"))) return rc;
-        // M[i, j] -= U[k,i]' U[k,j]   i, j > k, upper tiles only
-        GemmArgs u = skm_gemm_args(panel, panel, Mb + (long)(r0 + bs) * R + r0 + bs, rem, rem, bs, R, R, R);
-        u.transA = 1;
-        u.alpha = -1.0;
-        u.beta = 1.0;
-        u.tile_mask = 1;
-        u.sA = u.sB = u.sC = RR;
-        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, u, nb, st, "k_gemm_chol_update"))) return rc;
     }
     if (factor_only) return SKM_OK;   // block rows hold [W_k | U[k, j > k]]: enough for triangular solves
     // X = U^-1 in place, block rows bottom-up (diagonal blocks already hold W_i = U_ii^-1)

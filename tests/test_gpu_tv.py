@@ -253,3 +253,61 @@ def test_cosine_scoring_large_vs_oracle(sk, eng):
     sc = sk.cosine_scoring(enroll, test, ndx)
     ref = orc.cosine_scoring(enroll.stat1, test.stat1)
     assert np.abs(sc.scoremat - ref).max() < 1e-12
+
+
+def test_full_size_invariants_cfg5_shape(eng):
+    """BASELINE configs[4] shape (C=2048, D=60, R=400) at 600 sessions: too large for the oracle's per-session
+    loop, so the checks are properties that do not depend on the size --
+      * the linear system itself, (I + sum_c N_c T_c'T_c) e_h = T'f~ and diag(L^-1) + e_h^2, for three sessions
+        in host float64 (the oracle's formula, sidekit/factor_analyser.py:86-90);
+      * the solve path (no uncertainty) and the inverse path give the same i-vectors;
+      * accumulators are additive over session subsets and independent of the device batch;
+      * with sum_c N_sc = n for every session, sum_c A[c] = n * sum_s e_hh = n * _R (factor_analyser.py:124-126).
+    """
+    torch = eng.torch
+    C, D, R, S, n_tot = 2048, 60, 400, 600, 2000.0
+    gen = torch.Generator(device=eng.device)
+    gen.manual_seed(99)
+    post = torch.softmax(2.0 * torch.randn(S, C, generator=gen, device=eng.device, dtype=torch.float64), dim=1)
+    stat0 = (n_tot * post).to(torch.float32)
+    ft = torch.randn(S, C * D, generator=gen, device=eng.device) * torch.sqrt(stat0).repeat_interleave(D, dim=1)
+    naug = torch.zeros((S, eng.lib.skm_tv_naug_stride(C)), dtype=torch.float32, device=eng.device)
+    naug[:, :C] = stat0
+    naug[:, C] = 1.0
+    Th = 0.1 * np.random.RandomState(7).randn(C * D, R)
+    T32, G = eng.tv_prepare(dev(eng, Th), C, D)
+
+    def train(rows, batch):
+        A = torch.zeros((C + 1, R * R), dtype=torch.float64, device=eng.device)
+        Cc = torch.zeros((R, C * D), dtype=torch.float64, device=eng.device)
+        e, s = eng.tv_estep(naug[rows].contiguous(), ft[rows].contiguous(), T32, G, C, D, batch=batch, A_aug=A,
+                            Cacc=Cc, uncertainty=True)
+        return A, Cc, e, s
+    A, Cc, e_h, sig = train(slice(0, S), 256)
+    e_solve, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=512, uncertainty=False)
+    assert rel(eng.to_host(e_solve), eng.to_host(e_h)) < 1e-8
+
+    # the linear system, three sessions, host float64
+    e_host, s_host, n_host, f_host = eng.to_host(e_h), eng.to_host(sig), eng.to_host(stat0), eng.to_host(ft)
+    for s in (0, 311, S - 1):
+        nrep = np.repeat(n_host[s].astype(np.float64), D)
+        L = np.eye(R) + (Th.T * nrep).dot(Th)
+        rhs = Th.T.dot(f_host[s].astype(np.float64))
+        x = np.linalg.solve(L, rhs)
+        assert rel(e_host[s], x) < 1e-4, rel(e_host[s], x)
+        assert np.dot(e_host[s], x) / np.linalg.norm(e_host[s]) / np.linalg.norm(x) > 0.9999
+        assert rel(L.dot(e_host[s]), rhs) < 1e-4
+        assert rel(s_host[s], np.diag(np.linalg.inv(L)) + x * x) < 1e-4
+
+    # additivity over session subsets / independence of the device batch (float32 MFMA partial sums differ)
+    A1, C1, _, _ = train(slice(0, 250), 128)
+    A2, C2, _, _ = train(slice(250, S), 350)
+    iu = np.triu_indices(R)
+
+    def up(t):
+        return eng.to_host(t).reshape(-1, R, R)[:, iu[0], iu[1]]
+    assert rel(up(A1 + A2), up(A)) < 1e-5
+    assert rel(eng.to_host(C1 + C2), eng.to_host(Cc)) < 1e-5
+    # sum_c N_sc = n_tot for every session (float32 rounding of the posteriors aside)
+    Au = up(A)
+    assert rel(Au[:C].sum(0), n_tot * Au[C]) < 1e-5
