@@ -19,6 +19,7 @@ Also reported on the same JSON line (rank 0, N=1 detail):
                 sample of the same workload, host cores stated
   bw_stats      Baum-Welch N/F accumulation (configs[3] at reduced session count), frames/s
   tv            TV training iteration and i-vector extraction (configs[4] at reduced session count)
+  feat          feature post-processing in front of the path (RASTA, deltas, cmvn, VAD selection), HBM roofline
 """
 import argparse
 import json
@@ -112,8 +113,8 @@ def main():
     ap.add_argument("--tv-batch", type=int, default=2048, help="sessions per TV E-step batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (BW stats)")
-    ap.add_argument("--legs", default="bw,em2048,scoring,tv",
-                    help="secondary legs to run at N=1 (comma list of bw, em2048, scoring, tv)")
+    ap.add_argument("--legs", default="bw,em2048,scoring,feat,tv",
+                    help="secondary legs (comma list of bw, em2048, scoring, feat, tv)")
     args = ap.parse_args()
 
     import torch
@@ -321,6 +322,42 @@ def main():
                                        "workload": "cosine_scoring body, %d x %d i-vectors of rank 400 per GPU, float64" % (ne, ne),
                                        "f64_tflops": 2.0 * ne * ne * 400 / dtc / 1e12}
         del iv_e, iv_t
+
+    if "feat" in legs:
+        # ---- Feature post-processing in front of the path (FeaturesServer.post_processing, features_server.py:202-246;
+        # the experiment's configuration model_interface.py:45-52: RASTA + delta + double delta + cmvn), raw 20-dim
+        # cepstra + VAD labels in HBM -> normalised 60-dim float32 frames of the labelled rows.  HBM-bound streaming;
+        # sessions are sharded over ranks, no collective.
+        D0, Sf, Lf = 20, min(5000, T // 2000), 2000
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(99 + rank)
+        raw = 3.0 * torch.randn(Sf * Lf, D0, generator=gen, device=dev) + 5.0
+        vad = (torch.rand(Sf * Lf, generator=gen, device=dev) > 0.3).to(torch.uint8)
+        segf = np.arange(0, Sf + 1, dtype=np.int64) * Lf
+
+        def feat_all():
+            return eng.feat_postproc(raw, segf, label=vad, rasta=True, ndelta=2, norm=2, keep_all=False)
+        fo, _, _ = feat_all()
+        rows_out = int(fo.shape[0])
+        eng.profile(True)
+        dtf, _ = timed(feat_all, 3)
+        dtf /= 3
+        prof = eng.profile_read()
+        eng.profile(False)
+        ktf = {k: v[1] / v[0] for k, v in prof.items()}
+        # algorithmic bytes: raw frames and labels read once, labelled output rows and their labels written once
+        bytes_alg = Sf * Lf * (D0 * 4 + 1) + rows_out * (3 * D0 * 4 + 1)
+        t_w = ktf.get("k_feat_write", float("nan"))
+        result["feat"] = {"value": world * Sf * Lf / dtf, "unit": "frames/s", "n_gpus": world,
+                          "workload": "post_processing body (RASTA + delta + double delta + cmvn + VAD selection), "
+                                      "%d sessions x %d frames x %d raw dims per GPU -> %d-dim float32" % (Sf, Lf, D0, 3 * D0),
+                          "kernels_ms": {k: round(v, 3) for k, v in sorted(ktf.items())},
+                          "roofline": {"bound": "hbm", "kernel": "k_feat_write",
+                                       "achieved": bytes_alg / (t_w * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                       "frac": bytes_alg / (t_w * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_launch_ms": t_w,
+                                       "algorithmic_bytes_per_launch": bytes_alg},
+                          "path_GBps": bytes_alg / dtf / 1e9}
+        del raw, vad, fo
 
     if "tv" in legs:
         # ---- TV training iteration + i-vector extraction (BASELINE configs[4], fewer sessions): R=400, C=2048.

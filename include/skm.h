@@ -178,6 +178,35 @@ int skm_tv_mstep(void *ctx, double *A_aug_dev, const double *Cacc_dev, int C, in
  * (sidekit/iv_scoring.py:96-98); the score matrix itself (iv_scoring.py:99) is skm_gemm with transB. */
 int skm_row_normalize(void *ctx, double *X_dev, long S, int R, void *stream);
 
+/* ------------------------------------------------------------------ feature post-processing (next row) ---- */
+
+/* FeaturesServer.post_processing (sidekit/features_server.py:202-246) for a batch of S sessions whose raw
+ * frames are in HBM; session s owns rows [seg_off[s], seg_off[s+1]) of X (seg_off: S+1 int64, dev).
+ *   X_dev        raw frames, float32 (in_f64 = 0) or float64, row stride ldx elements
+ *   cols_dev     D0 int32 column indices = the server's `mask` (features_server.py:248-258), or NULL (0..D0-1)
+ *   label_dev    one byte per input row (VAD label), or NULL = every frame is speech
+ *   rasta        1: RASTA filter (frontend/normfeat.py:45-74); the first two labels of a session become its
+ *                third (features_server.py:322-323)
+ *   ndelta       0 / 1 / 2: append delta / delta + double delta (frontend/features.py:136-169: zero-padded
+ *                'same' convolution with the 7-tap filter, each rounded to float32 like the reference's
+ *                PARAM_TYPE array); delta_filter_host: 7 doubles on the host, NULL = features_server.py:129
+ *   norm         0 none, 1 cms, 2 cmvn (frontend/normfeat.py:77-126): per-session mean / population standard
+ *                deviation over the labelled frames, applied to every frame; gmean_dev / ginvstd_dev
+ *                (D0*(ndelta+1) doubles, ginvstd = 1/global_std) replace them when given
+ *   keep_all     1: every frame is written (row of frame t of session s = out_off[s] + t);
+ *                0: only labelled frames, compacted (features_server.py:241-244)
+ *   out_dev      [rows][D0*(ndelta+1)] float32 (out_f64 = 0) or float64; rows <= seg_off[S] - seg_off[0]
+ *   label_out_dev one byte per output row, or NULL;  out_off_dev: S+1 int64, out_off[S] = rows written
+ * Arithmetic is float64.  ws_dev needs skm_feat_workspace_bytes(S, D0, ndelta) bytes.
+ * 'stg' is broken in the reference (float slice indices, normfeat.py:166) and the sliding-window
+ * normalisations are not covered by this entry point. */
+size_t skm_feat_workspace_bytes(int S, int D0, int ndelta);
+int skm_feat_postproc(void *ctx, const void *X_dev, int in_f64, long ldx, const int *cols_dev, int D0,
+                      const uint8_t *label_dev, const int64_t *seg_off_dev, int S, int rasta, int ndelta,
+                      const double *delta_filter_host, int norm, const double *gmean_dev, const double *ginvstd_dev,
+                      int keep_all, void *out_dev, int out_f64, uint8_t *label_out_dev, int64_t *out_off_dev,
+                      void *ws_dev, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

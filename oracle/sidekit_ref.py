@@ -460,3 +460,79 @@ def cosine_scoring(enroll_iv, test_iv, wccn=None):
     e = (e.T / np.clip(np.linalg.norm(e, axis=1), 1e-8, np.inf)).T
     t = (t.T / np.clip(np.linalg.norm(t, axis=1), 1e-8, np.inf)).T
     return e.dot(t.T)
+
+
+# ----------------------------------------------------------------------------------------
+# Feature post-processing in front of the path: FeaturesServer.post_processing
+# ----------------------------------------------------------------------------------------
+DELTA_FILTER = np.array([.25, .5, .25, 0, -.25, -.5, -.25])      # sidekit/features_server.py:129
+
+
+def rasta_filt(x):
+    """sidekit/frontend/normfeat.py:45-74.  FIR numerator arange(.2, -.3, -.1), one pole at 0.94.  The first
+    four frames only prime the FIR state (their outputs are zero) and the recursion starts at frame 4 with
+    no feedback from the past: y[n] = sum_k b_k x[n-k] + 0.94 y[n-1], y[3] = 0."""
+    from scipy.signal import lfilter
+    x = np.asarray(x).T
+    numerator = np.arange(.2, -.3, -.1)
+    denominator = np.array([1, -0.94])
+    zf = np.zeros((x.shape[0], 4))
+    for i in range(x.shape[0]):
+        _, zf[i, :4] = lfilter(numerator, 1, x[i, :4], axis=-1, zi=[0, 0, 0, 0])
+    y = np.zeros(x.shape)
+    for i in range(y.shape[0]):
+        y[i, 4:] = lfilter(numerator, denominator, x[i, 4:], axis=-1, zi=zf[i, :])[0]
+    return y.T
+
+
+def compute_delta(features, filt=DELTA_FILTER):
+    """sidekit/frontend/features.py:136-169 ('filter' method).  The edge-padded copy the reference builds is
+    never used: the result is the zero-padded 'same' convolution with the 7-tap filter, stored in a float32
+    (PARAM_TYPE) array."""
+    features = np.asarray(features)
+    win = 3
+    delta = np.zeros((features.shape[0] + 2 * win, features.shape[1]), dtype=np.float32)
+    for i in range(features.shape[1]):
+        delta[:, i] = np.convolve(features[:, i], filt)
+    return delta[win:-win, :]
+
+
+def post_processing(feat, label, mask=None, rasta=False, delta=False, double_delta=False, delta_filter=DELTA_FILTER,
+                    feat_norm=None, keep_all_features=True, global_mean=None, global_std=None):
+    """FeaturesServer.post_processing (sidekit/features_server.py:202-246) for the options the device path
+    covers: mask (:248-258), RASTA (:308-324: the first two labels are copied from the third), delta /
+    double delta (:291-306), label_fusion (frontend/vad.py:400-419: the identity on a 1-D label vector,
+    whose elements it visits as 0-d arrays), 'cms' / 'cmvn' (frontend/normfeat.py:77-126; statistics over the
+    labelled frames, applied to every frame; population standard deviation), frame selection (:241-244).
+    Returns (features, labels)."""
+    feat = np.array(feat)
+    label = np.array(label, dtype=bool)
+    if mask is not None:
+        feat = feat[:, mask]
+    if rasta:
+        feat = rasta_filt(feat)
+        feat[:2, :] = feat[2, :]
+        label[:2] = label[2]
+    if delta:
+        d1 = compute_delta(feat, filt=delta_filter)
+        feat = np.column_stack((feat, d1))
+        if double_delta:
+            feat = np.column_stack((feat, compute_delta(d1, filt=delta_filter)))
+    if feat_norm == 'cms':
+        mu = global_mean if global_mean is not None else np.mean(feat[label, :], axis=0)
+        feat -= mu
+    elif feat_norm == 'cmvn':
+        if global_mean is not None and global_std is not None:
+            feat -= global_mean
+            feat /= global_std
+        elif not label.sum() == 0:
+            mu = np.mean(feat[label, :], axis=0)
+            stdev = np.std(feat[label, :], axis=0)
+            feat -= mu
+            feat /= stdev
+    elif feat_norm is not None:
+        raise NotImplementedError(feat_norm)
+    if not keep_all_features:
+        feat = feat[label]
+        label = label[label]
+    return feat, label

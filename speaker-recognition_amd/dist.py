@@ -2,6 +2,8 @@
 GPU box, gloo in the CPU tests.  Replaces sidekit/sidekit_mpi.py's Reduce/bcast pattern
 (sidekit_mpi.py:455-481, 186-214): every rank all-reduces ONE packed float64 buffer and then runs
 the identical deterministic M-step, so no broadcast is needed."""
+import os
+
 import numpy as np
 
 
@@ -11,9 +13,14 @@ def _td():
 
 
 def is_dist():
+    """True when torch.distributed is initialised with more than one rank.  SKM_FORCE_DIST=1 also takes the
+    collective code paths in a world of ONE rank (tests/test_gpu_rccl.py: the RCCL calls, buffer layouts and
+    the component-sharded M-step run for real on a single-GPU box)."""
     try:
         td = _td()
-        return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+        if not (td.is_available() and td.is_initialized()):
+            return False
+        return td.get_world_size() > 1 or os.environ.get("SKM_FORCE_DIST") == "1"
     except Exception:
         return False
 

@@ -56,6 +56,10 @@ SIGNATURES = {
                               _c_void_p, _c_size_t, _c_void_p]),
     "skm_moments_workspace_bytes": (_c_size_t, [_c_void_p, _c_int]),
     "skm_moments": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "skm_feat_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "skm_feat_postproc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_long, _c_void_p, _c_int, _c_void_p, _c_void_p,
+                                   _c_int, _c_int, _c_int, _dp, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p,
+                                   _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
 }
 
 _lib = None
@@ -257,6 +261,68 @@ class HipEngine(object):
         self._check(self.lib.skm_moments(self.ctx, _c_void_p(X.data_ptr()), T, D, _c_void_p(out.data_ptr()),
                                          _c_void_p(ws), need, self._stream()))
         return out
+
+    # ------------------------------------------------------------------ feature post-processing
+    def feat_postproc(self, X, seg_off, label=None, cols=None, rasta=False, ndelta=0, delta_filter=None, norm=0,
+                      global_mean=None, global_std=None, keep_all=True, out_dtype=None):
+        """FeaturesServer.post_processing of a batch of sessions resident in HBM (skm_feat_postproc).
+        X: (T x Draw) float32/float64 device tensor, session s = rows [seg_off[s], seg_off[s+1]).
+        Returns (out [rows x Dout], label_out uint8 [rows], out_off int64 [S+1]) device tensors; with
+        keep_all=False the rows are the labelled frames only (one host read of out_off[S] sizes the result)."""
+        torch = self.torch
+        assert X.dim() == 2 and X.dtype in (torch.float32, torch.float64) and X.stride(1) == 1
+        if not isinstance(seg_off, torch.Tensor):
+            seg_off = torch.as_tensor(np.asarray(seg_off, dtype=np.int64))
+        seg_off = seg_off.to(device=self.device, dtype=torch.int64).contiguous()
+        S = seg_off.numel() - 1
+        D0 = X.shape[1] if cols is None else len(cols)
+        cols_dev = None
+        if cols is not None:
+            cols = np.asarray(cols, dtype=np.int64)
+            if cols.size == 0:
+                raise Exception('filter list is empty')                        # features_server.py:255-256
+            if cols.min() < -X.shape[1] or cols.max() >= X.shape[1]:
+                raise IndexError("mask index out of range for %d columns" % X.shape[1])
+            cols_dev = torch.as_tensor(np.where(cols < 0, cols + X.shape[1], cols).astype(np.int32)).to(self.device)
+        dout = D0 * (ndelta + 1)
+        if label is not None:
+            if not isinstance(label, torch.Tensor):
+                label = torch.as_tensor(np.ascontiguousarray(np.asarray(label, dtype=np.uint8)))
+            label = label.to(device=self.device, dtype=torch.uint8).contiguous()
+            assert label.numel() == X.shape[0]
+        out_dtype = out_dtype or torch.float32
+        assert out_dtype in (torch.float32, torch.float64)
+        out = torch.empty((X.shape[0], dout), dtype=out_dtype, device=self.device)
+        lab_out = torch.empty(X.shape[0], dtype=torch.uint8, device=self.device)
+        out_off = torch.empty(S + 1, dtype=torch.int64, device=self.device)
+        gm = gi = None
+        if norm and global_mean is not None and (norm == 1 or global_std is not None):
+            gm = torch.as_tensor(_as_f64(global_mean)).to(self.device)
+            assert gm.numel() == dout
+            if norm == 2:
+                with np.errstate(divide="ignore"):
+                    gi = torch.as_tensor(1.0 / _as_f64(global_std)).to(self.device)
+                assert gi.numel() == dout
+        filt = None
+        if delta_filter is not None:
+            filt = _as_f64(delta_filter)
+            if filt.shape != (7,):
+                # numpy.convolve output would not fit the reference's (T + 6)-row array (features.py:154,167)
+                raise ValueError("could not broadcast: delta_filter must have 7 taps")
+        need = self.lib.skm_feat_workspace_bytes(S, D0, ndelta)
+        ws = self.workspace(need)
+        self._check(self.lib.skm_feat_postproc(
+            self.ctx, _c_void_p(X.data_ptr()), 1 if X.dtype == torch.float64 else 0, X.stride(0),
+            _c_void_p(cols_dev.data_ptr()) if cols_dev is not None else None, D0,
+            _c_void_p(label.data_ptr()) if label is not None else None, _c_void_p(seg_off.data_ptr()), S,
+            1 if rasta else 0, int(ndelta), filt.ctypes.data_as(_dp) if filt is not None else None, int(norm),
+            _c_void_p(gm.data_ptr()) if gm is not None else None, _c_void_p(gi.data_ptr()) if gi is not None else None,
+            1 if keep_all else 0, _c_void_p(out.data_ptr()), 1 if out_dtype == torch.float64 else 0,
+            _c_void_p(lab_out.data_ptr()), _c_void_p(out_off.data_ptr()), _c_void_p(ws), need, self._stream()))
+        if not keep_all:
+            rows = int(out_off[-1].item())
+            out, lab_out = out[:rows], lab_out[:rows]
+        return out, lab_out, out_off
 
     # ------------------------------------------------------------------ total variability
     GEMM_F32_F32, GEMM_F32_F64ACC, GEMM_F64_F64, GEMM_F64_F32OUT = 0, 1, 2, 3

@@ -144,7 +144,7 @@ class FactorAnalyser(object):
             eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, A_aug=A_aug, Cacc=Cacc)
         del G
         world = dist.world_size()
-        sharded = world > 1 and C % world == 0
+        sharded = dist.is_dist() and C % world == 0
         if sharded:
             # component-sharded M-step: reduce-scatter the accumulators so that rank g owns
             # components [g*C/W, (g+1)*C/W), all-reduce only _R (R*R doubles), solve locally, all-gather F rows.

@@ -1,22 +1,56 @@
 """Input boundary of the hot path: a features server hands frames to Mixture.EM_split and
 StatServer.accumulate_stat.  The reference's FeaturesServer (sidekit/features_server.py) reads
-HDF5 files and post-processes them on the host; that data plane is out of scope (SURVEY.md
-section 2, row 8).  This in-memory server keeps the two calls the hot path makes:
+HDF5 files and post-processes them on the host; file reading and feature extraction are out of
+scope.  This in-memory server keeps the calls the hot path makes:
 
     load(show, channel=0, input_feature_filename=None, label=None, start=None, stop=None)
         -> (T x D array, bool[T] VAD labels)                  (features_server.py:397-451)
     stack_features_parallel(show_list, ..., num_thread=1) -> N x D array   (features_server.py:603-666)
+    post_processing(feat, label, global_mean=None, global_std=None)         (features_server.py:202-246)
 
 plus the attributes accumulate_stat touches (keep_all_features, features_extractor,
 feature_filename_structure; statserver.py:631-645).  Values may be NumPy arrays or torch
 tensors already resident on the GPU.
+
+Post-processing (the step in front of the path) runs on the GPU through
+skm_feat_postproc: column mask, RASTA, delta / double delta, cms / cmvn, VAD selection -- the
+configuration of the reference's experiments (model_interface.py:45-52) included.  `load_batch`
+post-processes many sessions in one launch and leaves the frames in HBM for the statistics kernels.
+Not covered: 'stg' (broken in the reference: float slice indices, frontend/normfeat.py:166), the
+sliding-window normalisations, dct_pca / sdc / context / traps.
 """
+import re
+
 import numpy as np
+
+_NORMS = {None: 0, "cms": 1, "cmvn": 2}
+
+
+def parse_mask(mask):
+    """'[1-3,10,15-20]' -> [1, 2, 3, 10, 15, ..., 20]  (sidekit/sv_utils.py:377-394)."""
+    if not set(re.sub(r"\s", "", mask)[1:-1]).issubset(set("0123456789-,")):
+        raise Exception("Wrong mask format")
+    tmp = [k.split('-') for k in re.sub(r"[\s]", '', mask)[1:-1].split(',')]
+    indices = []
+    for seg in tmp:
+        if len(seg) == 1:
+            seg += seg
+        if len(seg) == 2:
+            indices += list(range(int(seg[0]), int(seg[1]) + 1))
+        else:
+            raise Exception("Wrong mask format")
+    return indices
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
 
 
 class FeaturesServer(object):
     def __init__(self, features=None, vad=None, features_extractor=None, feature_filename_structure=None,
-                 dataset_list=None, keep_all_features=True, is_sharded=False, **_ignored):
+                 dataset_list=None, mask=None, feat_norm=None, global_cmvn=None, delta=None, double_delta=None,
+                 delta_filter=None, rasta=None, keep_all_features=True, is_sharded=False, engine=None,
+                 dct_pca=False, sdc=False, context=None, traps_dct_nb=None, **_ignored):
         self.features = dict(features) if features is not None else {}
         self.vad = dict(vad) if vad is not None else {}
         self.features_extractor = features_extractor
@@ -25,24 +59,133 @@ class FeaturesServer(object):
         self.keep_all_features = keep_all_features
         # True when every rank of a multi-GPU job was given only ITS OWN frames already
         self.is_sharded = is_sharded
+        # post-processing options, defaults of features_server.py:119-133
+        self.mask = parse_mask(mask) if isinstance(mask, str) else (list(mask) if mask is not None else None)
+        self.feat_norm = feat_norm
+        self.global_cmvn = global_cmvn
+        self.delta = bool(delta) if delta is not None else False
+        self.double_delta = bool(double_delta) if double_delta is not None else False
+        self.delta_filter = np.array([.25, .5, .25, 0, -.25, -.5, -.25]) if delta_filter is None \
+            else np.asarray(delta_filter, dtype=np.float64)
+        self.rasta = bool(rasta) if rasta is not None else False
+        if dct_pca or sdc or (context is not None and tuple(context) != (0, 0)) or traps_dct_nb:
+            raise NotImplementedError("dct_pca / sdc / context / traps are outside the device post-processing path")
+        self._engine = engine
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            from .engine import default_engine
+            self._engine = default_engine()
+        return self._engine
 
     def add(self, show, cep, vad=None):
         self.features[show] = cep
         if vad is not None:
             self.vad[show] = np.asarray(vad, dtype=bool)
 
+    # ------------------------------------------------------------------ post-processing on the device
+    def has_post_processing(self):
+        return bool(self.mask is not None or self.rasta or self.delta or self.double_delta
+                    or self.feat_norm is not None)
+
+    def _options(self):
+        if self.feat_norm not in _NORMS:
+            if self.feat_norm == 'stg':
+                # the reference raises here as well (float slice indices, frontend/normfeat.py:166)
+                raise TypeError("slice indices must be integers or None or have an __index__ method")
+            if self.feat_norm in ('cmvn_sliding', 'cms_sliding'):
+                raise NotImplementedError("sliding-window normalisation is outside the device post-processing path")
+            norm = 0                                          # features_server.py:288-289: warning, no normalisation
+        else:
+            norm = _NORMS[self.feat_norm]
+        # features_server.py:298-305: double delta only on top of delta
+        ndelta = (2 if self.double_delta else 1) if self.delta else 0
+        return norm, ndelta
+
+    def _post_process_device(self, X, seg_off, label, keep_all, global_mean=None, global_std=None, out_dtype=None):
+        """Batch of sessions (device tensor X, seg_off host int64[S+1], label uint8/bool [rows] or None)
+        -> (out, label_out, out_off) device tensors."""
+        norm, ndelta = self._options()
+        seg = np.asarray(seg_off, dtype=np.int64)
+        if self.rasta and seg.size > 1 and (np.diff(seg) < 3).any():
+            # features_server.py:322: cep[2, :] of a session with fewer than three frames
+            raise IndexError("index 2 is out of bounds: RASTA needs at least 3 frames per session")
+        return self.engine.feat_postproc(X, seg, label=label, cols=self.mask, rasta=self.rasta, ndelta=ndelta,
+                                         delta_filter=self.delta_filter, norm=norm, global_mean=global_mean,
+                                         global_std=global_std, keep_all=keep_all, out_dtype=out_dtype)
+
+    def post_processing(self, feat, label, global_mean=None, global_std=None):
+        """One session (features_server.py:202-246).  NumPy in -> NumPy float64 out; a device tensor in ->
+        device tensors out (float32, the statistics kernels' input type)."""
+        eng = self.engine
+        torch = eng.torch
+        on_device = _is_torch(feat)
+        if on_device:
+            X = feat.to(eng.device)
+            if X.dtype not in (torch.float32, torch.float64):
+                X = X.to(torch.float32)
+        else:
+            a = np.asarray(feat)
+            if a.dtype not in (np.float32, np.float64):
+                a = a.astype(np.float64)
+            X = torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+        lab = None
+        if label is not None:
+            lab = label if _is_torch(label) else torch.from_numpy(np.ascontiguousarray(np.asarray(label, dtype=np.uint8)))
+        out, lab_out, _ = self._post_process_device(X, [0, X.shape[0]], lab, self.keep_all_features, global_mean,
+                                                    global_std, out_dtype=None if on_device else torch.float64)
+        if on_device:
+            return out, lab_out.to(torch.bool)
+        return eng.to_host(out), lab_out.cpu().numpy().astype(bool)
+
+    def load_batch(self, show_list, keep_all_features=None):
+        """Frames of many sessions, post-processed in ONE device pass and left in HBM:
+        (X float32 [rows x D] device tensor, seg_off int64 [S+1] NumPy, labels uint8 device tensor)."""
+        eng = self.engine
+        torch = eng.torch
+        keep_all = self.keep_all_features if keep_all_features is None else keep_all_features
+        blocks = [self.features[s] for s in show_list]
+        lens = np.array([b.shape[0] for b in blocks], dtype=np.int64)
+        seg = np.concatenate([[0], np.cumsum(lens)])
+        dev_blocks = [b.to(eng.device) if _is_torch(b) else torch.from_numpy(np.ascontiguousarray(np.asarray(b))).to(eng.device)
+                      for b in blocks]
+        dt = torch.float64 if any(b.dtype == torch.float64 for b in dev_blocks) else torch.float32
+        X = torch.cat([b.to(dt) for b in dev_blocks], dim=0) if len(dev_blocks) > 1 else dev_blocks[0].to(dt)
+        lab = None
+        if any(s in self.vad for s in show_list):
+            lab = torch.from_numpy(np.concatenate(
+                [np.asarray(self.vad[s], dtype=np.uint8) if s in self.vad else np.ones(n, dtype=np.uint8)
+                 for s, n in zip(show_list, lens)])).to(eng.device)
+        if not self.has_post_processing() and (keep_all or lab is None):
+            lab_out = lab if lab is not None else torch.ones(X.shape[0], dtype=torch.uint8, device=eng.device)
+            return X.to(torch.float32).contiguous(), seg, lab_out
+        out, lab_out, out_off = self._post_process_device(X.contiguous(), seg, lab, keep_all)
+        return out, out_off.cpu().numpy(), lab_out
+
+    # ------------------------------------------------------------------ the calls of the hot path
     def load(self, show, channel=0, input_feature_filename=None, label=None, start=None, stop=None):
         cep = self.features[show]
-        lab = self.vad.get(show)
+        lab = self.vad.get(show) if label is None else label
         if lab is None:
             lab = np.ones(cep.shape[0], dtype=bool)
         if start is not None or stop is not None:
             cep = cep[start:stop]
             lab = lab[start:stop]
+        if self.has_post_processing():
+            # the reference applies the mask once more after post_processing (features_server.py:495-496);
+            # here it is applied once
+            cep, lab = self.post_processing(cep, lab)
+        elif not self.keep_all_features and show in self.vad:
+            sel = np.asarray(lab, dtype=bool)                 # features_server.py:241-244, selection only
+            cep = cep[self.engine.torch.as_tensor(sel).to(cep.device)] if _is_torch(cep) else np.asarray(cep)[sel]
+            lab = lab[sel]
         return cep, lab
 
     def stack_features_parallel(self, show_list, channel_list=None, feature_filename_list=None, label_list=None,
                                 start_list=None, stop_list=None, num_thread=1):
+        if self.has_post_processing():
+            return self.load_batch(show_list)[0]
         blocks = [self.load(show)[0] for show in show_list]
         try:
             import torch

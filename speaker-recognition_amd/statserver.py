@@ -209,12 +209,37 @@ class StatServer(object):
             self.stat0[batch_idx, :] = eng.to_host(s0)
             self.stat1[batch_idx, :] = eng.to_host(s1)
 
-        for idx in mine:
+        def show_of(idx):
             show = self.segset[idx]
             channel = 0
             if feature_server.features_extractor is not None and show.endswith(channel_extension[1]):
                 channel = 1
-            show = show[:show.rfind(channel_extension[channel])]
+            return show[:show.rfind(channel_extension[channel])], channel
+
+        # Device data plane: a features server that post-processes on the GPU (skm_feat_postproc) hands over
+        # whole batches of sessions already VAD-selected in HBM -- same result as load() + cep[vad]
+        # (statserver.py:645-652: statistics over the labelled frames of the fully normalised session).
+        if getattr(feature_server, "has_post_processing", lambda: False)() and hasattr(feature_server, "load_batch") \
+                and all(self.start[i] is None and self.stop[i] is None for i in mine):
+            todo = list(mine)
+            while todo:
+                take, nfr = [], 0
+                while todo and (not take or nfr < max_batch_frames):
+                    i = todo.pop(0)
+                    take.append(i)
+                    nfr += feature_server.features[show_of(i)[0]].shape[0]
+                X, seg_off, _ = feature_server.load_batch([show_of(i)[0] for i in take], keep_all_features=False)
+                if not ubm.dim() == X.shape[1]:
+                    raise Exception('dimension of ubm and features differ: {:d} / {:d}'.format(ubm.dim(), X.shape[1]))
+                s0, s1 = eng.bw_stats(X, seg_off, packed)
+                self.stat0[take, :] = eng.to_host(s0)
+                self.stat1[take, :] = eng.to_host(s1)
+            mine_loop = []
+        else:
+            mine_loop = mine
+
+        for idx in mine_loop:
+            show, channel = show_of(idx)
             cep, vad = feature_server.load(show, channel=channel,
                                            input_feature_filename=feature_server.feature_filename_structure)
             if type(cep).__module__.startswith("torch"):

@@ -1,0 +1,110 @@
+"""The collective code paths on RCCL for real, on the one GPU this box has: torch.distributed is initialised
+with the "nccl" backend in a world of ONE rank and SKM_FORCE_DIST=1 makes the drop-in classes take every
+multi-GPU branch (all-reduce of the packed EM statistics, session sharding of accumulate_stat, the
+component-sharded TV M-step with reduce_scatter_tensor + all_gather, the i-vector row exchange, the sharded
+gmm_scoring).  Results must equal the plain single-process run of the same calls.  The world-size-2 logic is
+covered on CPU by tests/test_dist_gloo.py; this test pins the RCCL calls themselves (tensor layouts,
+contiguity, dtypes), which gloo cannot."""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import sidekit_ref as orc
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture()
+def rccl_world1():
+    import torch
+    import torch.distributed as td
+    assert not td.is_initialized()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    td.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    os.environ["SKM_FORCE_DIST"] = "1"
+    try:
+        yield td
+    finally:
+        os.environ.pop("SKM_FORCE_DIST", None)
+        torch.cuda.synchronize()
+        td.destroy_process_group()
+
+
+def _run_all(sk):
+    """EM_split, accumulate_stat, TV training (C divisible by the world: sharded M-step), extraction."""
+    g = golden("em_split.npz")
+    chunks = {"f%d" % i: g["chunk%d" % i] for i in range(4)}
+    fs = sk.FeaturesServer(features=chunks)
+    ubm = sk.Mixture()
+    llk = ubm.EM_split(features_server=fs, feature_list=list(chunks.keys()), distrib_nb=8, num_thread=1)
+    out = {"llk": np.array(llk), "w": ubm.w.copy(), "mu": ubm.mu.copy(), "invcov": ubm.invcov.copy()}
+
+    t = golden("tv.npz")
+    C, D, R = 16, 10, 6
+    tv_ubm = sk.Mixture()
+    tv_ubm.w, tv_ubm.mu, tv_ubm.invcov = t["w"].copy(), t["mu"].copy(), t["invcov"].copy()
+    tv_ubm.cov_var_ctl = 1.0 / tv_ubm.invcov
+    tv_ubm._compute_all()
+    a = golden("accumulate_stat.npz")
+    lens = [int(v) for v in a["lens"]]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    names = ["s%03d" % i for i in range(len(lens))]
+    fs2 = sk.FeaturesServer(features={n: a["frames"][off[i]:off[i + 1]] for i, n in enumerate(names)})
+    idmap = sk.IdMap()
+    idmap.leftids = np.array(["spk%d" % (i % 5) for i in range(len(lens))])
+    idmap.rightids = np.array(names)
+    idmap.start = np.empty(len(lens), "|O")
+    idmap.stop = np.empty(len(lens), "|O")
+    ss = sk.StatServer(idmap, ubm=tv_ubm)
+    ss.accumulate_stat(ubm=tv_ubm, feature_server=fs2, seg_indices=range(len(lens)))
+    out["stat0"], out["stat1"] = ss.stat0.copy(), ss.stat1.copy()
+
+    fa = sk.FactorAnalyser()
+    fa.total_variability_single(ss, tv_ubm, R, nb_iter=3, min_div=True, tv_init=t["tv_init"].copy(), batch_size=7)
+    out["F"] = fa.F.copy()
+    ivs, sig = fa.extract_ivectors(tv_ubm, ss, batch_size=7, uncertainty=True)
+    out["iv"], out["iv_sigma"] = ivs.stat1.copy(), sig.copy()
+    return out
+
+
+def test_rccl_paths_equal_single_process(rccl_world1):
+    import sidekit_amd as sk
+    dist = sk.package.dist
+    assert dist.is_dist() and dist.world_size() == 1 and dist.rank() == 0
+    with_rccl = _run_all(sk)
+    os.environ.pop("SKM_FORCE_DIST")
+    assert not dist.is_dist()
+    plain = _run_all(sk)
+    for k in plain:
+        # the same kernels on the same data: sums over one rank are exact, so equality is bit-wise
+        assert np.array_equal(with_rccl[k], plain[k]), k
+    # and both match the reference (golden) as the plain path is already required to
+    t = golden("tv.npz")
+    assert np.abs(with_rccl["F"] - t["F_it3"]).max() / np.abs(t["F_it3"]).max() < 1e-3
+
+
+def test_rccl_collective_helpers(rccl_world1):
+    import torch
+    import sidekit_amd as sk
+    dist = sk.package.dist
+    dev = torch.device("cuda", torch.cuda.current_device())
+    x = torch.arange(24, dtype=torch.float64, device=dev).reshape(6, 4)
+    assert torch.equal(dist.allreduce_sum_(x.clone()), x)
+    assert torch.equal(dist.reduce_scatter_rows(x.clone()), x)
+    # a permuted (non-contiguous) view, as the Cacc column blocks are handed over
+    v = x.view(2, 3, 4).permute(1, 0, 2)
+    assert torch.equal(dist.reduce_scatter_rows(v.contiguous().view(6, 4)), v.contiguous().view(6, 4))
+    assert torch.equal(dist.allgather_rows(x, [6]), x)
+    assert dist.shard_bounds(10) == (0, 10)

@@ -203,3 +203,48 @@ def test_cosine_scoring_oracle_and_host_logic_vs_reference_golden():
     s, sw, g = _cosine_case(sk, OracleEngine())
     close(s, g["scoremat"], rtol=1e-12)
     close(sw, g["scoremat_wccn"], rtol=1e-12)
+
+
+def _pp_cases():
+    g = golden("post_processing.npz")
+    for i in range(int(g["n_cases"])):
+        o = g["case%d_opt" % i]
+        kw = dict(rasta=bool(o[0]), delta=bool(o[1]), double_delta=bool(o[2]), feat_norm=[None, "cms", "cmvn"][o[3]],
+                  keep_all_features=bool(o[4]),
+                  mask=g["case%d_mask" % i] if ("case%d_mask" % i) in g.files else None,
+                  global_mean=g["case%d_gmean" % i] if ("case%d_gmean" % i) in g.files else None,
+                  global_std=g["case%d_gstd" % i] if ("case%d_gstd" % i) in g.files else None)
+        yield i, g["case%d_x" % i], g["case%d_label" % i], kw, g["case%d_feat" % i], g["case%d_lab" % i]
+
+
+def test_post_processing_oracle_vs_reference_golden():
+    """FeaturesServer.post_processing of the real reference (RASTA, delta, double delta, cms/cmvn, mask, global
+    statistics, frame selection, degenerate sessions whose variance is zero -> inf/NaN): the restatement makes the
+    same NumPy/SciPy calls, so it is bit-identical wherever the reference's output is finite."""
+    n = 0
+    for i, x, label, kw, feat, lab in _pp_cases():
+        with np.errstate(all="ignore"):
+            f, l = orc.post_processing(x, label, **kw)
+        assert f.shape == feat.shape and f.dtype == feat.dtype, i
+        assert np.array_equal(l, lab), i
+        assert np.array_equal(f, feat, equal_nan=True), i
+        n += 1
+    assert n == 11
+
+
+def test_post_processing_closed_forms():
+    """What the device kernel implements, stated directly: RASTA = 5-tap FIR primed by frames 0..3 + pole 0.94
+    started at frame 4; delta = zero-padded 'same' convolution rounded to float32."""
+    rs = np.random.RandomState(3)
+    x = rs.randn(50, 3)
+    y = orc.rasta_filt(x)
+    b = np.arange(.2, -.3, -.1)
+    ref = np.zeros_like(x)
+    for n in range(4, 50):
+        ref[n] = sum(b[k] * x[n - k] for k in range(5)) + 0.94 * ref[n - 1]
+    assert np.abs(y - ref).max() < 1e-14
+    d = orc.compute_delta(x)
+    f = orc.DELTA_FILTER
+    xp = np.vstack([np.zeros((3, 3)), x, np.zeros((3, 3))])
+    ref = np.array([sum(f[k] * xp[t + 6 - k] for k in range(7)) for t in range(50)]).astype(np.float32)
+    assert d.dtype == np.float32 and np.array_equal(d, ref)

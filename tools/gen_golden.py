@@ -348,10 +348,69 @@ def gen_cosine(sidekit):
     print("cosine", sc.scoremat.shape, list(sc.modelset), list(sc.segset))
 
 
+def gen_post_processing(sidekit):
+    """FeaturesServer.post_processing (features_server.py:202-246) on a few synthetic sessions: the experiment's
+    configuration (model_interface.py:45-52: RASTA + delta + double delta + cmvn, all frames kept) and the other
+    option combinations the device path covers.  Cases are stored as case<i>_{opt,x,label,feat,lab}."""
+    rs = np.random.RandomState(91)
+    out, n = {}, 0
+    cases = [
+        dict(rasta=True, delta=True, double_delta=True, feat_norm="cmvn", keep_all_features=True, T=311, D=20),
+        dict(rasta=True, delta=True, double_delta=True, feat_norm="cmvn", keep_all_features=False, T=97, D=7),
+        dict(rasta=False, delta=True, double_delta=True, feat_norm="cms", keep_all_features=False, T=150, D=13),
+        dict(rasta=False, delta=True, double_delta=False, feat_norm="cmvn", keep_all_features=True, T=64, D=5),
+        dict(rasta=True, delta=False, double_delta=False, feat_norm=None, keep_all_features=False, T=40, D=3),
+        dict(rasta=False, delta=False, double_delta=False, feat_norm="cmvn", keep_all_features=True, T=33, D=4),
+        dict(rasta=True, delta=True, double_delta=True, feat_norm="cmvn", keep_all_features=True, T=5, D=2),
+        dict(rasta=False, delta=True, double_delta=True, feat_norm="cmvn", keep_all_features=True, T=1, D=2),
+        dict(rasta=False, delta=True, double_delta=True, feat_norm="cmvn", keep_all_features=False, T=50, D=6,
+             mask="[1-3,5]"),
+        dict(rasta=True, delta=True, double_delta=True, feat_norm="cmvn", keep_all_features=True, T=80, D=4,
+             use_global=True),
+        dict(rasta=False, delta=True, double_delta=True, feat_norm="cmvn", keep_all_features=True, T=30, D=3,
+             no_speech=True),
+    ]
+    for c in cases:
+        T, D = c["T"], c["D"]
+        x = 3.0 * rs.randn(T, D) + 5.0 * rs.randn(1, D) + np.cumsum(0.3 * rs.randn(T, D), axis=0)
+        label = rs.rand(T) > 0.35
+        if c.get("no_speech"):
+            label[:] = False
+        elif not label.any():
+            label[0] = True
+        fs = sidekit.FeaturesServer(dataset_list=["cep"], mask=c.get("mask"), feat_norm=c["feat_norm"],
+                                    delta=c["delta"], double_delta=c["double_delta"], rasta=c["rasta"],
+                                    keep_all_features=c["keep_all_features"])
+        gm = gs = None
+        if c.get("use_global"):
+            dout = D * (1 + int(c["delta"]) + int(c["delta"] and c["double_delta"]))
+            gm, gs = rs.randn(dout), rs.uniform(0.5, 2.0, size=dout)
+        feat, lab = fs.post_processing(x.copy(), label.copy(), gm, gs)
+        opt = np.array([int(c["rasta"]), int(c["delta"]), int(c["double_delta"]),
+                        {None: 0, "cms": 1, "cmvn": 2}[c["feat_norm"]], int(c["keep_all_features"])])
+        out["case%d_opt" % n] = opt
+        out["case%d_x" % n] = x
+        out["case%d_label" % n] = label
+        out["case%d_feat" % n] = np.asarray(feat)
+        out["case%d_lab" % n] = np.asarray(lab)
+        if c.get("mask"):
+            out["case%d_mask" % n] = np.array(fs.mask)
+        if gm is not None:
+            out["case%d_gmean" % n] = gm
+            out["case%d_gstd" % n] = gs
+        print("post_processing case", n, c, "->", np.asarray(feat).shape, np.asarray(feat).dtype)
+        n += 1
+    out["n_cases"] = np.array(n)
+    np.savez_compressed(os.path.join(OUT, "post_processing.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "cosine":
         gen_cosine(import_reference())
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "postproc":
+        gen_post_processing(import_reference())
         return
     if len(sys.argv) > 1 and sys.argv[1] == "scoring":
         gen_gmm_scoring(import_reference())
@@ -367,6 +426,7 @@ def main():
         gen_stats_and_tv(sidekit, tmp)
     gen_gmm_scoring(sidekit)
     gen_cosine(sidekit)
+    gen_post_processing(sidekit)
 
 
 if __name__ == "__main__":
