@@ -355,8 +355,15 @@ def main():
                           "roofline": {"bound": "hbm", "kernel": "k_feat_write",
                                        "achieved": bytes_alg / (t_w * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                        "frac": bytes_alg / (t_w * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_launch_ms": t_w,
-                                       "algorithmic_bytes_per_launch": bytes_alg},
+                                       "algorithmic_bytes_per_launch": bytes_alg, "traffic": None},
                           "path_GBps": bytes_alg / dtf / 1e9}
+        # HBM bytes of the write walk from the committed rocprofv3 --pmc passes of this same leg
+        pmc_feat = os.path.join(ROOT, "profiles", "r1_pmc_feat.json")
+        if os.path.exists(pmc_feat) and (Sf, Lf, D0) == (5000, 2000, 20):
+            for name, rec in json.load(open(pmc_feat))["kernels"].items():
+                if name.startswith("k_feat_walk<2, 1, 1"):
+                    result["feat"]["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                    result["feat"]["roofline"]["traffic_source"] = "profiles/r1_pmc_feat.json (FETCH_SIZE x2 + WRITE_SIZE)"
         del raw, vad, fo
 
     if "tv" in legs:

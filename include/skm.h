@@ -197,12 +197,14 @@ int skm_row_normalize(void *ctx, double *X_dev, long S, int R, void *stream);
  *                0: only labelled frames, compacted (features_server.py:241-244)
  *   out_dev      [rows][D0*(ndelta+1)] float32 (out_f64 = 0) or float64; rows <= seg_off[S] - seg_off[0]
  *   label_out_dev one byte per output row, or NULL;  out_off_dev: S+1 int64, out_off[S] = rows written
- * Arithmetic is float64.  ws_dev needs skm_feat_workspace_bytes(S, D0, ndelta) bytes.
+ *   T            rows of the batch, >= seg_off[S] - seg_off[0] (sizes the chunk tables: sessions are cut into
+ *                256-frame chunks, one lane per chunk and column)
+ * Arithmetic is float64.  ws_dev needs skm_feat_workspace_bytes(T, S, D0, ndelta) bytes.
  * 'stg' is broken in the reference (float slice indices, normfeat.py:166) and the sliding-window
  * normalisations are not covered by this entry point. */
-size_t skm_feat_workspace_bytes(int S, int D0, int ndelta);
+size_t skm_feat_workspace_bytes(long T, int S, int D0, int ndelta);
 int skm_feat_postproc(void *ctx, const void *X_dev, int in_f64, long ldx, const int *cols_dev, int D0,
-                      const uint8_t *label_dev, const int64_t *seg_off_dev, int S, int rasta, int ndelta,
+                      const uint8_t *label_dev, const int64_t *seg_off_dev, int S, long T, int rasta, int ndelta,
                       const double *delta_filter_host, int norm, const double *gmean_dev, const double *ginvstd_dev,
                       int keep_all, void *out_dev, int out_f64, uint8_t *label_out_dev, int64_t *out_off_dev,
                       void *ws_dev, size_t ws_bytes, void *stream);

@@ -6,21 +6,40 @@
 // (frontend/normfeat.py:77-126) and the selection of the VAD-labelled frames (:241-244), so that the frames
 // the E-step and Baum-Welch kernels read never visit the host.
 //
-// The work is HBM-bound streaming (a 5-tap FIR + one pole, two 7-tap FIRs and an affine map per value).
-// One lane owns one (session, column) pair and walks the session's frames in order, which keeps the
-// recursion of the RASTA pole and the running count of labelled frames private to the lane; adjacent lanes
-// own adjacent columns, so a wave reads and writes whole rows.  Two walks: `k_feat_stats` (mean and
-// standard deviation over the labelled frames; skipped without cms/cmvn or with global statistics) and
-// `k_feat_write` (recomputes the filters -- cheaper than a round trip of the 3x wider un-normalised
-// matrix through HBM -- and stores the normalised rows, compacted when only labelled frames are kept).
-// All arithmetic is float64; deltas are rounded to float32 where the reference stores them in a float32
-// array (frontend/features.py:159).  No atomics: results are bit-identical from run to run.
+// The work is HBM-bound streaming (a 5-tap FIR + one pole, two 7-tap FIRs and an affine map per value), with
+// float64 VALU work of the same order.  Sessions are cut into chunks of FEAT_L frames; one lane owns one
+// (chunk, column) pair and walks its frames in order, adjacent lanes own adjacent columns, so a wave reads and
+// writes whole rows and a 2000-frame session gives 8x more waves than lanes-per-session would.  What crosses a
+// chunk boundary is made explicit:
+//   * the RASTA pole: `k_feat_carry` computes every chunk's zero-state response at its last frame; the state a
+//     chunk starts from is E[j-1] + a^L E[j-2] + a^2L E[j-3] (0.94^768 < 1e-20: three terms are exact in float64);
+//   * the delta windows: a chunk starts its walk 6 frames early and runs 3*ndelta frames past its end;
+//   * the row index of compacted output: labelled frames are counted per chunk and scanned over the batch;
+//   * mean / variance: per-chunk (n, mean, M2) merged in chunk order (Chan et al.) by `k_feat_combine`.
+// Two walks over the frames: `k_feat_stats` (skipped without cms/cmvn or with global statistics) and
+// `k_feat_write` (recomputes the filters -- cheaper than a round trip of the 3x wider un-normalised matrix
+// through HBM -- and stores the normalised rows).  All arithmetic is float64; deltas are rounded to float32
+// where the reference stores them in a float32 array (frontend/features.py:159).  No atomics anywhere:
+// results are bit-identical from run to run.
 #include "skm_common.h"
 
+#define FEAT_L 256     // frames per chunk
+#define FEAT_H 6       // frames of history a chunk re-walks (two 7-tap windows)
+#define FEAT_PF 8      // frames a lane loads ahead of the one it is working on
+
 struct FeatFilt {
-    double b[5];   // RASTA numerator
-    double pole;   // 0.94
-    double f[7];   // delta filter
+    double b[5];    // RASTA numerator
+    double pole;    // 0.94
+    double poleL;   // pole^FEAT_L        (carry across a full chunk)
+    double poleL0;  // pole^(FEAT_L - FEAT_H)  (carry across chunk 0, which is FEAT_H frames shorter)
+    double f[7];    // delta filter
+};
+
+struct FeatItem {
+    int s;          // session
+    long j;         // chunk of the session
+    long base, T;   // first row of the session in X, its length
+    long n0, n1;    // frames [n0, n1) of the session are this chunk's
 };
 
 __device__ __forceinline__ double feat_load(const void *X, int in_f64, long idx)
@@ -36,176 +55,46 @@ __device__ __forceinline__ bool feat_label(const uint8_t *lab, long base, long t
     return lab[base + t] != 0;
 }
 
-// MODE 0: statistics (mu, 1/sd per session and output column).  MODE 1: write.
-template <int NDELTA, int RASTA, int MODE>
-__global__ __launch_bounds__(256) void k_feat_walk(
-    const void *__restrict__ X, int in_f64, long ldx, const int *__restrict__ cols,
-    const uint8_t *__restrict__ lab, const int64_t *__restrict__ seg_off, int S, int D0, FeatFilt ff,
-    int norm,                      // 0 none, 1 cms, 2 cmvn
-    double *__restrict__ mu, double *__restrict__ isd, long stat_stride,   // [S or 1][Dout]; stride 0 = global
-    const int64_t *__restrict__ out_off, int keep_all, void *__restrict__ out, int out_f64,
-    uint8_t *__restrict__ lab_out)
+// item -> (session, chunk): largest s with chunk_base[s] <= item (sessions without frames own no chunk).
+__device__ __forceinline__ bool feat_item(const int64_t *__restrict__ chunk_base, const int64_t *__restrict__ seg_off,
+                                          int S, long item, FeatItem &it)
 {
-    constexpr int LA = 3 * NDELTA;          // frames of look-ahead before a row is complete
-    constexpr int NO = NDELTA + 1;          // output blocks: [static | delta | double delta]
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (long)S * D0) return;
-    const int s = (int)(g / D0), c = (int)(g % D0);
-    const long base = seg_off[s];
-    const long T = seg_off[s + 1] - base;
-    if (T <= 0) return;
-    const int col = cols ? cols[c] : c;
-    const int Dout = NO * D0;
-
-    double xw[5] = {0, 0, 0, 0, 0};
-    double yprev = 0.0;
-    double yw[7] = {0, 0, 0, 0, 0, 0, 0};
-    float dw[7] = {0, 0, 0, 0, 0, 0, 0};
-
-    // MODE 0 accumulators: sums of (v - shift) and (v - shift)^2 over the labelled frames
-    double sh[NO], m1[NO], m2[NO];
-#pragma unroll
-    for (int k = 0; k < NO; ++k) sh[k] = m1[k] = m2[k] = 0.0;
-    long nlab = 0;
-
-    // MODE 1 constants
-    double cm[NO], ci[NO];
-#pragma unroll
-    for (int k = 0; k < NO; ++k) {
-        cm[k] = 0.0;
-        ci[k] = 1.0;
+    if (item >= chunk_base[S]) return false;
+    int lo = 0, hi = S;                       // invariant: chunk_base[lo] <= item < chunk_base[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (chunk_base[mid] <= item) lo = mid;
+        else hi = mid;
     }
-    long row0 = 0;
-    if constexpr (MODE == 1) {
-        if (norm) {
-#pragma unroll
-            for (int k = 0; k < NO; ++k) {
-                cm[k] = mu[(long)s * stat_stride + k * D0 + c];
-                ci[k] = isd[(long)s * stat_stride + k * D0 + c];
-            }
-        }
-        row0 = out_off[s];
-    }
+    it.s = lo;
+    it.j = item - chunk_base[lo];
+    it.base = seg_off[lo];
+    it.T = seg_off[lo + 1] - it.base;
+    it.n0 = it.j * FEAT_L;
+    it.n1 = (it.n0 + FEAT_L < it.T) ? it.n0 + FEAT_L : it.T;
+    return true;
+}
 
-    for (long n = 0; n < T + LA; ++n) {
-        double y = 0.0;
-        if (n < T) {
-            const double x = feat_load(X, in_f64, (base + n) * ldx + col);
-            if (RASTA) {
-                xw[0] = xw[1]; xw[1] = xw[2]; xw[2] = xw[3]; xw[3] = xw[4]; xw[4] = x;
-                if (n >= 4) {
-                    // normfeat.py:64-72: frames 0..3 only prime the FIR state; the pole starts at frame 4
-                    y = ff.b[0] * xw[4] + ff.b[1] * xw[3] + ff.b[2] * xw[2] + ff.b[3] * xw[1] + ff.b[4] * xw[0]
-                        + ff.pole * yprev;
-                }
-                yprev = y;
-            } else {
-                y = x;
-            }
-        }
-        double v[3] = {0.0, 0.0, 0.0};
-        if constexpr (NDELTA == 0) {
-            v[0] = y;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) yw[k] = yw[k + 1];
-            yw[6] = y;
-            float d = 0.f;
-            const long td = n - 3;
-            if (td >= 0 && td < T) {
-                double a = 0.0;
-#pragma unroll
-                for (int k = 0; k < 7; ++k) a += ff.f[k] * yw[6 - k];
-                d = (float)a;                               // features.py:159,167: stored in a float32 array
-            }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) dw[k] = dw[k + 1];
-            dw[6] = d;
-            v[0] = yw[6 - LA];
-            v[1] = (double)dw[6 - (LA - 3)];
-            if constexpr (NDELTA == 2) {
-                double a = 0.0;
-#pragma unroll
-                for (int k = 0; k < 7; ++k) a += ff.f[k] * (double)dw[6 - k];
-                v[2] = (double)(float)a;
-            }
-        }
-        const long te = n - LA;
-        if (te < 0) continue;
-        const bool on = feat_label(lab, base, te, T, RASTA);
-        if constexpr (MODE == 0) {
-            if (on) {
-                if (nlab == 0) {
-#pragma unroll
-                    for (int k = 0; k < NO; ++k) sh[k] = v[k];
-                }
-#pragma unroll
-                for (int k = 0; k < NO; ++k) {
-                    const double dd = v[k] - sh[k];
-                    m1[k] += dd;
-                    m2[k] += dd * dd;
-                }
-                ++nlab;
-            }
-        } else {
-            if (keep_all || on) {
-                const long row = row0 + (keep_all ? te : nlab);
-#pragma unroll
-                for (int k = 0; k < NO; ++k) {
-                    const double o = (v[k] - cm[k]) * ci[k];
-                    const long oi = row * Dout + k * D0 + c;
-                    if (out_f64) static_cast<double *>(out)[oi] = o;
-                    else static_cast<float *>(out)[oi] = (float)o;
-                }
-                if (c == 0 && lab_out) lab_out[row] = on ? 1 : 0;
-                if (on) ++nlab;
-            }
-        }
-    }
+// first frame of the RASTA recursion interval of chunk j (intervals tile the session; chunk 0's is shorter)
+__device__ __forceinline__ long feat_b(long j) { return j == 0 ? 0 : j * FEAT_L - FEAT_H; }
 
-    if constexpr (MODE == 0) {
-#pragma unroll
-        for (int k = 0; k < NO; ++k) {
-            double mean, inv;
-            if (nlab == 0 && norm == 2) {
-                mean = 0.0;                                 // normfeat.py:122: cmvn leaves a session without speech alone
-                inv = 1.0;
-            } else {
-                const double nn = (double)nlab;             // cms without speech: 0/0 = NaN like numpy.mean of nothing
-                const double a = m1[k] / nn;
-                mean = sh[k] + a;
-                double var = m2[k] / nn - a * a;
-                if (var < 0.0) var = 0.0;
-                inv = (norm == 2) ? 1.0 / sqrt(var) : 1.0;  // numpy.std: population standard deviation
-            }
-            mu[(long)s * stat_stride + k * D0 + c] = mean;
-            isd[(long)s * stat_stride + k * D0 + c] = inv;
-        }
+// chunks per session
+__global__ __launch_bounds__(256) void k_feat_nchunks(const int64_t *__restrict__ seg_off, int S, int64_t *__restrict__ nch)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S) {
+        const long T = seg_off[s + 1] - seg_off[s];
+        nch[s] = T > 0 ? (T + FEAT_L - 1) / FEAT_L : 0;
     }
 }
 
-// Labelled frames per session (one wave per session), with the RASTA label fix.
-__global__ __launch_bounds__(256) void k_feat_count(const uint8_t *__restrict__ lab, const int64_t *__restrict__ seg_off,
-                                                     int S, int rasta, int64_t *__restrict__ cnt)
-{
-    const int lane = threadIdx.x & 63;
-    const long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= S) return;
-    const long base = seg_off[s], T = seg_off[s + 1] - base;
-    long n = 0;
-    for (long t = lane; t < T; t += 64) n += feat_label(lab, base, t, T, rasta) ? 1 : 0;
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) n += __shfl_xor(n, m);
-    if (lane == 0) cnt[s] = n;
-}
-
-// Exclusive scan of cnt[S] into off[S+1] (one workgroup; S is a session count).
-__global__ __launch_bounds__(1024) void k_feat_scan(const int64_t *__restrict__ cnt, int S, int64_t *__restrict__ off)
+// Exclusive scan of cnt[n] into off[n+1] (one workgroup).
+__global__ __launch_bounds__(1024) void k_feat_scan(const int64_t *__restrict__ cnt, long n, int64_t *__restrict__ off)
 {
     __shared__ long part[1024];
     const int t = threadIdx.x;
-    const long per = ((long)S + 1023) / 1024;
-    const long a = (long)t * per, b = (a + per < S) ? a + per : S;
+    const long per = (n + 1023) / 1024;
+    const long a = (long)t * per < n ? (long)t * per : n, b = (a + per < n) ? a + per : n;
     long sum = 0;
     for (long i = a; i < b; ++i) sum += cnt[i];
     part[t] = sum;
@@ -221,27 +110,327 @@ __global__ __launch_bounds__(1024) void k_feat_scan(const int64_t *__restrict__ 
         off[i] = run;
         run += cnt[i];
     }
-    if (t == 1023) off[S] = part[1023];
+    if (t == 1023) off[n] = part[1023];
 }
 
-// off[s] = seg_off[s] - seg_off[0] (all frames kept: output rows mirror the input rows of the batch)
-__global__ __launch_bounds__(256) void k_feat_rebase(const int64_t *__restrict__ seg_off, int S, int64_t *__restrict__ off)
+// Labelled frames per chunk (one wave per item), with the RASTA label fix; 0 for items past the end.
+__global__ __launch_bounds__(256) void k_feat_count(const uint8_t *__restrict__ lab, const int64_t *__restrict__ seg_off,
+                                                     const int64_t *__restrict__ chunk_base, int S, long items_max,
+                                                     int rasta, int64_t *__restrict__ cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= items_max) return;
+    FeatItem it;
+    long n = 0;
+    if (feat_item(chunk_base, seg_off, S, item, it)) {
+        for (long t = it.n0 + lane; t < it.n1; t += 64) n += feat_label(lab, it.base, t, it.T, rasta) ? 1 : 0;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) n += __shfl_xor(n, m);
+    if (lane == 0) cnt[item] = n;
+}
+
+// out_off[s]: first output row of session s (S+1 entries)
+__global__ __launch_bounds__(256) void k_feat_outoff(const int64_t *__restrict__ seg_off, const int64_t *__restrict__ chunk_base,
+                                                      const int64_t *__restrict__ row_base, int S, int keep_all,
+                                                      int64_t *__restrict__ off)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= S) off[i] = seg_off[i] - seg_off[0];
+    if (i <= S) off[i] = keep_all ? seg_off[i] - seg_off[0] : row_base[chunk_base[i]];
 }
 
-template <int MODE>
-static void feat_launch(int ndelta, int rasta, dim3 grid, hipStream_t st, const void *X, int in_f64, long ldx,
-                        const int *cols, const uint8_t *lab, const int64_t *seg_off, int S, int D0, const FeatFilt &ff,
-                        int norm, double *mu, double *isd, long stat_stride, const int64_t *out_off, int keep_all,
-                        void *out, int out_f64, uint8_t *lab_out)
+// Zero-state response of the RASTA filter over a chunk's recursion interval, at the interval's last frame.
+__global__ __launch_bounds__(256) void k_feat_carry(const void *__restrict__ X, int in_f64, long ldx,
+                                                     const int *__restrict__ cols, const int64_t *__restrict__ seg_off,
+                                                     const int64_t *__restrict__ chunk_base, int S, int D0, long items_max,
+                                                     FeatFilt ff, double *__restrict__ E)
 {
-#define SKM_FEAT_CASE(ND, RA)                                                                                        \
-    if (ndelta == ND && rasta == RA) {                                                                               \
-        hipLaunchKernelGGL((k_feat_walk<ND, RA, MODE>), grid, dim3(256), 0, st, X, in_f64, ldx, cols, lab, seg_off, \
-                           S, D0, ff, norm, mu, isd, stat_stride, out_off, keep_all, out, out_f64, lab_out);        \
-        return;                                                                                                      \
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long item = g / D0;
+    const int c = (int)(g % D0);
+    if (item >= items_max) return;
+    FeatItem it;
+    if (!feat_item(chunk_base, seg_off, S, item, it)) return;
+    const long b0 = feat_b(it.j), b1 = feat_b(it.j + 1);
+    if (b1 >= it.T) return;                   // the last chunk of a session hands nothing on
+    const int col = cols ? cols[c] : c;
+    double xw[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 1; k <= 4; ++k)
+        if (b0 - k >= 0) xw[5 - k] = feat_load(X, in_f64, (it.base + b0 - k) * ldx + col);
+    double y = 0.0;
+    auto loadx = [&](long n) -> double {                    // clamped: always a legal address
+        return feat_load(X, in_f64, (it.base + (n < it.T ? n : it.T - 1)) * ldx + col);
+    };
+    double xq[FEAT_PF], xn[FEAT_PF];
+#pragma unroll
+    for (int u = 0; u < FEAT_PF; ++u) xq[u] = loadx(b0 + u);
+    for (long nb = b0; nb < b1; nb += FEAT_PF) {
+#pragma unroll
+        for (int u = 0; u < FEAT_PF; ++u) xn[u] = loadx(nb + FEAT_PF + u);
+#pragma unroll
+        for (int u = 0; u < FEAT_PF; ++u) {
+            const long n = nb + u;
+            xw[0] = xw[1]; xw[1] = xw[2]; xw[2] = xw[3]; xw[3] = xw[4];
+            xw[4] = xq[u];
+            const double yn = ff.b[0] * xw[4] + ff.b[1] * xw[3] + ff.b[2] * xw[2] + ff.b[3] * xw[1] + ff.b[4] * xw[0]
+                              + ff.pole * y;
+            y = (n >= b1) ? y : ((n >= 4) ? yn : 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < FEAT_PF; ++u) xq[u] = xn[u];
+    }
+    E[item * D0 + c] = y;
+}
+
+// MODE 0: per-chunk statistics (n, mean, M2 per output column).  MODE 1: write.
+// The frame loop is kept free of divergent branches (every lane of a wave walks another chunk): loads are made
+// unconditional by clamping the frame index, every "outside the session" case is a select, and the walk is cut
+// into a warm-up that emits nothing and a main loop that emits every frame.
+template <int NDELTA, int RASTA, int MODE, int IN64, int OUT64>
+__global__ __launch_bounds__(256) void k_feat_walk(
+    const void *__restrict__ X, long ldx, const int *__restrict__ cols,
+    const uint8_t *__restrict__ lab, const int64_t *__restrict__ seg_off, const int64_t *__restrict__ chunk_base,
+    int S, int D0, long items_max, FeatFilt ff, const double *__restrict__ E,
+    int64_t *__restrict__ part_n, double *__restrict__ part,                  // MODE 0 out: [item], [item][Dout][2]
+    int norm, const double *__restrict__ mu, const double *__restrict__ isd, long stat_stride,   // MODE 1 in
+    const int64_t *__restrict__ row_base, int keep_all, void *__restrict__ out, uint8_t *__restrict__ lab_out)
+{
+    constexpr int LA = 3 * NDELTA;          // frames of look-ahead before a row is complete
+    constexpr int NO = NDELTA + 1;          // output blocks: [static | delta | double delta]
+    constexpr int XB = IN64 ? 8 : 4, OB = OUT64 ? 8 : 4;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long item = g / D0;
+    const int c = (int)(g % D0);
+    if (item >= items_max) return;
+    FeatItem it;
+    if (!feat_item(chunk_base, seg_off, S, item, it)) return;
+    const int col = cols ? cols[c] : c;
+    const int Dout = NO * D0;
+    const long T = it.T, base = it.base, n0 = it.n0;
+    const long w0 = feat_b(it.j);           // the walk starts FEAT_H frames before the chunk
+    const char *xcol = static_cast<const char *>(X) + (base * ldx + col) * XB;
+    const long xstep = ldx * XB;
+    auto loadx = [&](long n) -> double {
+        const char *p = xcol + (n < T ? n : T - 1) * xstep;
+        return IN64 ? *reinterpret_cast<const double *>(p) : (double)*reinterpret_cast<const float *>(p);
+    };
+
+    double xw[5] = {0, 0, 0, 0, 0};         // x[n-4 .. n]
+    double yw[7] = {0, 0, 0, 0, 0, 0, 0};   // y[n-6 .. n]
+    double dw[7] = {0, 0, 0, 0, 0, 0, 0};   // delta[n-9 .. n-3]
+    double yprev = 0.0;
+    if constexpr (RASTA != 0) {
+        if (it.j > 0) {
+#pragma unroll
+            for (int k = 1; k <= 4; ++k) xw[5 - k] = (w0 - k >= 0) ? loadx(w0 - k) : 0.0;
+            // state of the pole at frame w0 - 1: the last three intervals (0.94^768 < 1e-20)
+            yprev = E[(item - 1) * D0 + c];
+            if (it.j >= 2) {
+                const double p1 = (it.j - 1 == 0) ? ff.poleL0 : ff.poleL;       // length of interval j-1
+                double tail = E[(item - 2) * D0 + c];
+                if (it.j >= 3) tail += ((it.j - 2 == 0) ? ff.poleL0 : ff.poleL) * E[(item - 3) * D0 + c];
+                yprev += p1 * tail;
+            }
+        }
+    }
+
+    // one frame step: consumes frame n, leaves the completed row of frame n - LA in v
+    auto step = [&](long n, double x, double (&v)[3]) {
+        double y;
+        if constexpr (RASTA != 0) {
+            xw[0] = xw[1]; xw[1] = xw[2]; xw[2] = xw[3]; xw[3] = xw[4]; xw[4] = x;
+            // normfeat.py:64-72: frames 0..3 only prime the FIR state; the pole starts at frame 4
+            y = ff.b[0] * xw[4] + ff.b[1] * xw[3] + ff.b[2] * xw[2] + ff.b[3] * xw[1] + ff.b[4] * xw[0] + ff.pole * yprev;
+            y = (n >= 4 && n < T) ? y : 0.0;
+            yprev = y;
+        } else {
+            y = (n < T) ? x : 0.0;
+        }
+        if constexpr (NDELTA == 0) {
+            v[0] = y;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) yw[k] = yw[k + 1];
+            yw[6] = y;
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) a += ff.f[k] * yw[6 - k];
+            const long td = n - 3;
+            // features.py:159,167: the convolution is stored in a float32 array; zero outside the session
+            const double d = (td >= 0 && td < T) ? (double)(float)a : 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dw[k] = dw[k + 1];
+            dw[6] = d;
+            v[0] = yw[6 - LA];
+            v[1] = dw[6 - (LA - 3)];
+            if constexpr (NDELTA == 2) {
+                double a2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) a2 += ff.f[k] * dw[6 - k];
+                v[2] = (double)(float)a2;
+            }
+        }
+    };
+
+    // The frame loop runs in blocks of FEAT_PF frames: the loads of the next block are issued before the current
+    // block is processed, so every lane keeps FEAT_PF loads in flight (a lane's own chain of dependent steps would
+    // otherwise expose the full HBM latency once per frame).  Frames before n0 + LA only fill the windows.
+    double v[3] = {0.0, 0.0, 0.0};
+    const long n_emit = n0 + LA, n_end = it.n1 + LA;
+    double xq[FEAT_PF], xn[FEAT_PF];
+#pragma unroll
+    for (int u = 0; u < FEAT_PF; ++u) xq[u] = loadx(w0 + u);
+
+    if constexpr (MODE == 0) {
+        double sh[NO], m1[NO], m2[NO];      // sums of (v - shift), (v - shift)^2 over the labelled frames
+#pragma unroll
+        for (int k = 0; k < NO; ++k) sh[k] = m1[k] = m2[k] = 0.0;
+        long nlab = 0;
+        for (long nb = w0; nb < n_end; nb += FEAT_PF) {
+#pragma unroll
+            for (int u = 0; u < FEAT_PF; ++u) xn[u] = loadx(nb + FEAT_PF + u);
+#pragma unroll
+            for (int u = 0; u < FEAT_PF; ++u) {
+                const long n = nb + u;
+                if (n < n_end) {
+                    step(n, xq[u], v);
+                    const bool on = n >= n_emit && feat_label(lab, base, n >= n_emit ? n - LA : n0, T, RASTA);
+                    const bool first = on && nlab == 0;
+#pragma unroll
+                    for (int k = 0; k < NO; ++k) {
+                        sh[k] = first ? v[k] : sh[k];      // shift = the chunk's first labelled value
+                        const double dd = on ? v[k] - sh[k] : 0.0;
+                        m1[k] += dd;
+                        m2[k] += dd * dd;
+                    }
+                    nlab += on ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FEAT_PF; ++u) xq[u] = xn[u];
+        }
+        if (c == 0) part_n[item] = nlab;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) {
+            double mean = 0.0, M2 = 0.0;
+            if (nlab > 0) {
+                const double nn = (double)nlab;
+                mean = sh[k] + m1[k] / nn;
+                M2 = m2[k] - m1[k] * m1[k] / nn;
+                if (M2 < 0.0) M2 = 0.0;
+            }
+            part[(item * Dout + k * D0 + c) * 2 + 0] = mean;
+            part[(item * Dout + k * D0 + c) * 2 + 1] = M2;
+        }
+    } else {
+        double cm[NO], ci[NO];              // the affine map of this session and column
+#pragma unroll
+        for (int k = 0; k < NO; ++k) {
+            cm[k] = norm ? mu[(long)it.s * stat_stride + k * D0 + c] : 0.0;
+            ci[k] = norm ? isd[(long)it.s * stat_stride + k * D0 + c] : 1.0;
+        }
+        long orow = keep_all ? (base - seg_off[0]) + n0 : row_base[item];
+        char *op = static_cast<char *>(out) + (orow * Dout + c) * OB;
+        const long ostep = (long)Dout * OB, oblk = (long)D0 * OB;
+        for (long nb = w0; nb < n_end; nb += FEAT_PF) {
+#pragma unroll
+            for (int u = 0; u < FEAT_PF; ++u) xn[u] = loadx(nb + FEAT_PF + u);
+#pragma unroll
+            for (int u = 0; u < FEAT_PF; ++u) {
+                const long n = nb + u;
+                if (n < n_end) {
+                    step(n, xq[u], v);
+                    if (n >= n_emit) {
+                        const bool on = feat_label(lab, base, n - LA, T, RASTA);
+                        if (keep_all || on) {
+#pragma unroll
+                            for (int k = 0; k < NO; ++k) {
+                                const double o = (v[k] - cm[k]) * ci[k];
+                                if constexpr (OUT64 != 0) *reinterpret_cast<double *>(op + k * oblk) = o;
+                                else *reinterpret_cast<float *>(op + k * oblk) = (float)o;
+                            }
+                            if (c == 0 && lab_out) lab_out[orow] = on ? 1 : 0;
+                            op += ostep;
+                            ++orow;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FEAT_PF; ++u) xq[u] = xn[u];
+        }
+    }
+}
+
+// Per session and output column: merge the chunks' (n, mean, M2) in chunk order, emit mean and 1/std.
+__global__ __launch_bounds__(256) void k_feat_combine(const int64_t *__restrict__ chunk_base, const int64_t *__restrict__ part_n,
+                                                       const double *__restrict__ part, int S, int Dout, int norm,
+                                                       double *__restrict__ mu, double *__restrict__ isd)
+{
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long)S * Dout) return;
+    const int s = (int)(g / Dout), kc = (int)(g % Dout);
+    double n = 0.0, mean = 0.0, M2 = 0.0;
+    for (long item = chunk_base[s]; item < chunk_base[s + 1]; ++item) {
+        const double nb = (double)part_n[item];
+        if (nb == 0.0) continue;
+        const double mb = part[(item * Dout + kc) * 2], Mb = part[(item * Dout + kc) * 2 + 1];
+        if (n == 0.0) {
+            n = nb; mean = mb; M2 = Mb;
+        } else {
+            const double d = mb - mean, nt = n + nb;
+            mean += d * (nb / nt);
+            M2 += Mb + d * d * (n * nb / nt);
+            n = nt;
+        }
+    }
+    double m_out, inv;
+    if (n == 0.0 && norm == 2) {
+        m_out = 0.0;                                // normfeat.py:122: cmvn leaves a session without speech alone
+        inv = 1.0;
+    } else {
+        m_out = (n == 0.0) ? (0.0 / n) : mean;      // cms without speech: NaN like numpy.mean of nothing
+        inv = (norm == 2) ? 1.0 / sqrt(M2 / n) : 1.0;   // numpy.std: population standard deviation
+    }
+    mu[g] = m_out;
+    isd[g] = inv;
+}
+
+struct FeatWs {
+    int64_t *nch, *chunk_base, *cnt, *row_base, *part_n;
+    double *E, *part, *mu, *isd;
+    size_t bytes;
+};
+
+static FeatWs feat_ws(char *p, long T, int S, int D0, int ndelta)
+{
+    const size_t items = (size_t)(T / FEAT_L) + (size_t)S + 1;
+    const size_t dout = (size_t)D0 * (ndelta + 1);
+    FeatWs w;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += skm_align_up(n, 256); return p + at; };
+    w.nch = reinterpret_cast<int64_t *>(take(((size_t)S + 1) * 8));
+    w.chunk_base = reinterpret_cast<int64_t *>(take(((size_t)S + 1) * 8));
+    w.cnt = reinterpret_cast<int64_t *>(take(items * 8));
+    w.row_base = reinterpret_cast<int64_t *>(take((items + 1) * 8));
+    w.part_n = reinterpret_cast<int64_t *>(take(items * 8));
+    w.E = reinterpret_cast<double *>(take(items * D0 * 8));
+    w.part = reinterpret_cast<double *>(take(items * dout * 16));
+    w.mu = reinterpret_cast<double *>(take((size_t)S * dout * 8));
+    w.isd = reinterpret_cast<double *>(take(((size_t)S + 1) * dout * 8));
+    w.bytes = o;
+    return w;
+}
+
+template <int MODE, int IN64, int OUT64, typename... Args>
+static void feat_launch2(int ndelta, int rasta, dim3 grid, hipStream_t st, Args... args)
+{
+#define SKM_FEAT_CASE(ND, RA)                                                                              \
+    if (ndelta == ND && rasta == RA) {                                                                     \
+        hipLaunchKernelGGL((k_feat_walk<ND, RA, MODE, IN64, OUT64>), grid, dim3(256), 0, st, args...);    \
+        return;                                                                                            \
     }
     SKM_FEAT_CASE(0, 0)
     SKM_FEAT_CASE(0, 1)
@@ -252,30 +441,41 @@ static void feat_launch(int ndelta, int rasta, dim3 grid, hipStream_t st, const 
 #undef SKM_FEAT_CASE
 }
 
-extern "C" size_t skm_feat_workspace_bytes(int S, int D0, int ndelta)
+template <int MODE, typename... Args>
+static void feat_launch(int ndelta, int rasta, int in64, int out64, dim3 grid, hipStream_t st, Args... args)
 {
-    if (S < 0 || D0 <= 0 || ndelta < 0 || ndelta > 2) return 0;
-    const size_t dout = (size_t)D0 * (ndelta + 1);
-    return skm_align_up((size_t)S * dout * 8, 256) * 2 + skm_align_up(((size_t)S + 1) * 8, 256);
+    if (MODE == 0) out64 = 0;               // the statistics walk stores nothing in the output type
+    if (in64 && out64) feat_launch2<MODE, 1, 1>(ndelta, rasta, grid, st, args...);
+    else if (in64) feat_launch2<MODE, 1, 0>(ndelta, rasta, grid, st, args...);
+    else if (out64) feat_launch2<MODE, 0, 1>(ndelta, rasta, grid, st, args...);
+    else feat_launch2<MODE, 0, 0>(ndelta, rasta, grid, st, args...);
+}
+
+extern "C" size_t skm_feat_workspace_bytes(long T, int S, int D0, int ndelta)
+{
+    if (T < 0 || S < 0 || D0 <= 0 || ndelta < 0 || ndelta > 2) return 0;
+    return feat_ws(nullptr, T, S, D0, ndelta).bytes;
 }
 
 extern "C" int skm_feat_postproc(void *ctx_, const void *X_dev, int in_f64, long ldx, const int *cols_dev, int D0,
-                                 const uint8_t *label_dev, const int64_t *seg_off_dev, int S, int rasta, int ndelta,
-                                 const double *delta_filter_host, int norm, const double *gmean_dev,
+                                 const uint8_t *label_dev, const int64_t *seg_off_dev, int S, long T, int rasta,
+                                 int ndelta, const double *delta_filter_host, int norm, const double *gmean_dev,
                                  const double *ginvstd_dev, int keep_all, void *out_dev, int out_f64,
                                  uint8_t *label_out_dev, int64_t *out_off_dev, void *ws_dev, size_t ws_bytes,
                                  void *stream)
 {
     SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
     hipStream_t st = (hipStream_t)stream;
-    SKM_REQUIRE(ctx && S >= 0 && D0 > 0 && ldx >= D0, "skm_feat_postproc: bad shape (S=%d, D0=%d, ldx=%ld)", S, D0, ldx);
+    SKM_REQUIRE(ctx && S >= 0 && T >= 0 && D0 > 0 && ldx >= D0, "skm_feat_postproc: bad shape (S=%d, T=%ld, D0=%d, ldx=%ld)",
+                S, T, D0, ldx);
     SKM_REQUIRE(ndelta >= 0 && ndelta <= 2 && norm >= 0 && norm <= 2 && (rasta == 0 || rasta == 1),
                 "skm_feat_postproc: bad option (rasta=%d, ndelta=%d, norm=%d)", rasta, ndelta, norm);
-    SKM_REQUIRE(seg_off_dev && out_off_dev && (S == 0 || (X_dev && out_dev)), "skm_feat_postproc: NULL pointer");
+    SKM_REQUIRE(seg_off_dev && out_off_dev && (T == 0 || (X_dev && out_dev)), "skm_feat_postproc: NULL pointer");
     SKM_REQUIRE(norm != 2 || (gmean_dev == nullptr) == (ginvstd_dev == nullptr),
                 "skm_feat_postproc: cmvn takes both global statistics or none");
-    SKM_REQUIRE((long)S * D0 < (1L << 31) * 256, "skm_feat_postproc: too many (session, column) pairs");
-    if (ws_bytes < skm_feat_workspace_bytes(S, D0, ndelta)) {
+    const long items_max = T / FEAT_L + S;                   // >= sum_s ceil(T_s / FEAT_L)
+    SKM_REQUIRE((items_max * D0 + 255) / 256 < (1L << 31), "skm_feat_postproc: too many (chunk, column) pairs");
+    if (ws_bytes < skm_feat_workspace_bytes(T, S, D0, ndelta)) {
         skm_set_error("skm_feat_postproc: workspace too small");
         return SKM_ERR_WORKSPACE;
     }
@@ -283,55 +483,71 @@ extern "C" int skm_feat_postproc(void *ctx_, const void *X_dev, int in_f64, long
     // numpy.arange(.2, -.3, -.1) as the reference builds it (normfeat.py:54): start + i*step in float64
     for (int i = 0; i < 5; ++i) ff.b[i] = 0.2 + i * -0.1;
     ff.pole = 0.94;
+    ff.poleL = pow(0.94, (double)FEAT_L);
+    ff.poleL0 = pow(0.94, (double)(FEAT_L - FEAT_H));
     static const double dflt[7] = {.25, .5, .25, 0, -.25, -.5, -.25};          // features_server.py:129
     for (int i = 0; i < 7; ++i) ff.f[i] = delta_filter_host ? delta_filter_host[i] : dflt[i];
 
-    if (S == 0) {
-        SKM_HIP(hipMemsetAsync(out_off_dev, 0, 8, st));
+    if (S == 0 || T == 0) {
+        SKM_HIP(hipMemsetAsync(out_off_dev, 0, ((size_t)S + 1) * 8, st));
         return SKM_OK;
     }
-    const size_t dout = (size_t)D0 * (ndelta + 1);
-    char *ws = static_cast<char *>(ws_dev);
-    double *mu = reinterpret_cast<double *>(ws);
-    double *isd = reinterpret_cast<double *>(ws + skm_align_up((size_t)S * dout * 8, 256));
-    int64_t *cnt = reinterpret_cast<int64_t *>(ws + 2 * skm_align_up((size_t)S * dout * 8, 256));
-    long stat_stride = (long)dout;
-    const bool global = norm && gmean_dev && (norm == 1 || ginvstd_dev);
-    const dim3 grid((unsigned)(((long)S * D0 + 255) / 256));
-
-    if (keep_all) {
-        SkmProfScope ps(ctx, "k_feat_rebase", st);
-        hipLaunchKernelGGL(k_feat_rebase, dim3((S + 256) / 256), dim3(256), 0, st, seg_off_dev, S, out_off_dev);
-    } else {
-        SkmProfScope ps(ctx, "k_feat_count_scan", st);
-        hipLaunchKernelGGL(k_feat_count, dim3((S + 3) / 4), dim3(256), 0, st, label_dev, seg_off_dev, S, rasta, cnt);
-        hipLaunchKernelGGL(k_feat_scan, dim3(1), dim3(1024), 0, st, cnt, S, out_off_dev);
+    const int dout = D0 * (ndelta + 1);
+    FeatWs w = feat_ws(static_cast<char *>(ws_dev), T, S, D0, ndelta);
+    const dim3 grid((unsigned)((items_max * D0 + 255) / 256));
+    {
+        SkmProfScope ps(ctx, "k_feat_index", st);
+        hipLaunchKernelGGL(k_feat_nchunks, dim3((S + 255) / 256), dim3(256), 0, st, seg_off_dev, S, w.nch);
+        hipLaunchKernelGGL(k_feat_scan, dim3(1), dim3(1024), 0, st, w.nch, (long)S, w.chunk_base);
+        if (!keep_all) {
+            hipLaunchKernelGGL(k_feat_count, dim3((unsigned)((items_max + 3) / 4)), dim3(256), 0, st, label_dev, seg_off_dev,
+                               w.chunk_base, S, items_max, rasta, w.cnt);
+            hipLaunchKernelGGL(k_feat_scan, dim3(1), dim3(1024), 0, st, w.cnt, items_max, w.row_base);
+        }
+        hipLaunchKernelGGL(k_feat_outoff, dim3((S + 256) / 256), dim3(256), 0, st, seg_off_dev, w.chunk_base, w.row_base, S,
+                           keep_all, out_off_dev);
+        SKM_HIP(hipGetLastError());
     }
-    SKM_HIP(hipGetLastError());
-    const double *mu_use = mu, *isd_use = isd;
+    if (rasta) {
+        SkmProfScope ps(ctx, "k_feat_carry", st);
+        hipLaunchKernelGGL(k_feat_carry, grid, dim3(256), 0, st, X_dev, in_f64, ldx, cols_dev, seg_off_dev, w.chunk_base, S,
+                           D0, items_max, ff, w.E);
+        SKM_HIP(hipGetLastError());
+    }
+    const double *mu_use = w.mu, *isd_use = w.isd;
+    long stat_stride = dout;
+    const bool global = norm && gmean_dev && (norm == 1 || ginvstd_dev);
     if (global) {
         // global statistics (normfeat.py:93-94, :116-120): one row for every session; cms has no scale
         mu_use = gmean_dev;
-        isd_use = (norm == 2) ? ginvstd_dev : nullptr;
+        isd_use = ginvstd_dev;
         stat_stride = 0;
         if (norm == 1) {
-            // a row of ones for the scale
             std::vector<double> ones(dout, 1.0);
-            SKM_HIP(hipMemcpyAsync(isd, ones.data(), dout * 8, hipMemcpyHostToDevice, st));
+            SKM_HIP(hipMemcpyAsync(w.isd, ones.data(), (size_t)dout * 8, hipMemcpyHostToDevice, st));
             SKM_HIP(hipStreamSynchronize(st));
-            isd_use = isd;
+            isd_use = w.isd;
         }
     } else if (norm) {
-        SkmProfScope ps(ctx, "k_feat_stats", st);
-        feat_launch<0>(ndelta, rasta, grid, st, X_dev, in_f64, ldx, cols_dev, label_dev, seg_off_dev, S, D0, ff, norm,
-                       mu, isd, stat_stride, nullptr, 1, nullptr, 0, nullptr);
+        {
+            SkmProfScope ps(ctx, "k_feat_stats", st);
+            feat_launch<0>(ndelta, rasta, in_f64, 0, grid, st, X_dev, ldx, cols_dev, label_dev, seg_off_dev,
+                           (const int64_t *)w.chunk_base, S, D0, items_max, ff, (const double *)w.E, w.part_n, w.part, norm,
+                           (const double *)nullptr, (const double *)nullptr, 0L, (const int64_t *)nullptr, 1,
+                           (void *)nullptr, (uint8_t *)nullptr);
+            SKM_HIP(hipGetLastError());
+        }
+        SkmProfScope ps(ctx, "k_feat_combine", st);
+        hipLaunchKernelGGL(k_feat_combine, dim3((unsigned)(((long)S * dout + 255) / 256)), dim3(256), 0, st, w.chunk_base,
+                           w.part_n, w.part, S, dout, norm, w.mu, w.isd);
         SKM_HIP(hipGetLastError());
     }
     {
         SkmProfScope ps(ctx, "k_feat_write", st);
-        feat_launch<1>(ndelta, rasta, grid, st, X_dev, in_f64, ldx, cols_dev, label_dev, seg_off_dev, S, D0, ff, norm,
-                       const_cast<double *>(mu_use), const_cast<double *>(isd_use), stat_stride, out_off_dev, keep_all,
-                       out_dev, out_f64, label_out_dev);
+        feat_launch<1>(ndelta, rasta, in_f64, out_f64, grid, st, X_dev, ldx, cols_dev, label_dev, seg_off_dev,
+                       (const int64_t *)w.chunk_base, S, D0, items_max, ff, (const double *)w.E, (int64_t *)nullptr,
+                       (double *)nullptr, norm, mu_use, isd_use, stat_stride, (const int64_t *)w.row_base, keep_all, out_dev,
+                       label_out_dev);
         SKM_HIP(hipGetLastError());
     }
     return SKM_OK;

@@ -56,9 +56,9 @@ SIGNATURES = {
                               _c_void_p, _c_size_t, _c_void_p]),
     "skm_moments_workspace_bytes": (_c_size_t, [_c_void_p, _c_int]),
     "skm_moments": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
-    "skm_feat_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "skm_feat_workspace_bytes": (_c_size_t, [_c_long, _c_int, _c_int, _c_int]),
     "skm_feat_postproc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_long, _c_void_p, _c_int, _c_void_p, _c_void_p,
-                                   _c_int, _c_int, _c_int, _dp, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p,
+                                   _c_int, _c_long, _c_int, _c_int, _dp, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p,
                                    _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
 }
 
@@ -309,13 +309,13 @@ class HipEngine(object):
             if filt.shape != (7,):
                 # numpy.convolve output would not fit the reference's (T + 6)-row array (features.py:154,167)
                 raise ValueError("could not broadcast: delta_filter must have 7 taps")
-        need = self.lib.skm_feat_workspace_bytes(S, D0, ndelta)
+        need = self.lib.skm_feat_workspace_bytes(X.shape[0], S, D0, ndelta)
         ws = self.workspace(need)
         self._check(self.lib.skm_feat_postproc(
             self.ctx, _c_void_p(X.data_ptr()), 1 if X.dtype == torch.float64 else 0, X.stride(0),
             _c_void_p(cols_dev.data_ptr()) if cols_dev is not None else None, D0,
             _c_void_p(label.data_ptr()) if label is not None else None, _c_void_p(seg_off.data_ptr()), S,
-            1 if rasta else 0, int(ndelta), filt.ctypes.data_as(_dp) if filt is not None else None, int(norm),
+            X.shape[0], 1 if rasta else 0, int(ndelta), filt.ctypes.data_as(_dp) if filt is not None else None, int(norm),
             _c_void_p(gm.data_ptr()) if gm is not None else None, _c_void_p(gi.data_ptr()) if gi is not None else None,
             1 if keep_all else 0, _c_void_p(out.data_ptr()), 1 if out_dtype == torch.float64 else 0,
             _c_void_p(lab_out.data_ptr()), _c_void_p(out_off.data_ptr()), _c_void_p(ws), need, self._stream()))

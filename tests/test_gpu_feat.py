@@ -60,10 +60,10 @@ def test_post_processing_vs_reference_golden(sk):
 @pytest.mark.parametrize("keep_all", [True, False])
 @pytest.mark.parametrize("in_dtype", [np.float32, np.float64])
 def test_batch_of_ragged_sessions_vs_oracle(sk, keep_all, in_dtype):
-    """One launch over many sessions of different length (3 ... 700 frames, one without speech, one fully
-    speech), experiment configuration (RASTA + delta + double delta + cmvn), float32 frames out."""
+    """One launch over many sessions of different length (3 ... 2000 frames = 1 ... 8 chunks of 256 with every
+    boundary case of the chunk hand-over, one without speech, one fully speech), experiment configuration (RASTA + delta + double delta + cmvn), float32 frames out."""
     rs = np.random.RandomState(5)
-    lens = [3, 4, 5, 9, 64, 65, 257, 700, 31, 100] + [int(v) for v in rs.randint(10, 300, size=30)]
+    lens = [3, 4, 5, 9, 64, 65, 257, 700, 31, 100, 256, 512, 1030, 2000, 262, 263] + [int(v) for v in rs.randint(10, 300, size=30)]
     D0 = 20
     fs = sk.FeaturesServer(feat_norm="cmvn", delta=True, double_delta=True, rasta=True, keep_all_features=keep_all)
     shows, ref_f, ref_l = [], [], []
