@@ -101,6 +101,56 @@ def cpu_baseline(C, D, seconds_target=15.0):
                       % (C, D, frames, n_chunks, dt)}
 
 
+def _host_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return int(max([p.get("num_threads", 1) for p in threadpool_info()] or [1]))
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
+def cpu_baseline_bw(C, D, seconds_target=8.0):
+    """The oracle's accumulate_stat body (reference call sequence per session: 2 dot + exp passes + 1 dot) on a
+    bounded number of 2000-frame sessions."""
+    from oracle import sidekit_ref as orc
+    gmm = orc.random_gmm(C, D, seed=11)
+    sess = orc.synth_frames(2000, dim=D, seed=1234).astype(np.float64)
+    t0 = time.perf_counter()
+    orc.accumulate_stat(gmm, [sess])
+    probe = time.perf_counter() - t0
+    n = int(max(8, min(64, seconds_target / max(probe, 1e-3))))
+    t0 = time.perf_counter()
+    orc.accumulate_stat(gmm, [sess] * n)
+    dt = time.perf_counter() - t0
+    return {"value": 2000 * n / dt, "unit": "frames/s", "cores": _host_threads(), "kind": "port",
+            "sample": "oracle (NumPy f64) accumulate_stat, C=%d D=%d, %d sessions x 2000 frames, %.1f s" % (C, D, n, dt)}
+
+
+def cpu_baseline_tv(C, D, R, seconds_target=10.0):
+    """The oracle's e_on_batch (the reference's per-session (F.T * n).dot(F) + inv, factor_analyser.py:86-90) on a
+    bounded number of sessions; it is the body of both TV training and extract_ivectors."""
+    from oracle import sidekit_ref as orc
+    gmm = orc.random_gmm(C, D, seed=11)
+    rs = np.random.RandomState(3)
+    Fm = 0.1 * rs.randn(C * D, R)
+
+    def stats(n):
+        s0 = (2000.0 * rs.dirichlet(np.full(C, 0.3), size=n)).astype(np.float32)
+        s1 = (np.repeat(s0, D, axis=1) * gmm.mu.flatten() + rs.randn(n, C * D)).astype(np.float32)
+        return s0, s1
+    s0, s1 = stats(1)
+    t0 = time.perf_counter()
+    orc.e_on_batch(s0, s1, gmm, Fm)
+    probe = time.perf_counter() - t0
+    n = int(max(1, min(32, seconds_target / max(probe, 1e-3))))
+    s0, s1 = stats(n)
+    t0 = time.perf_counter()
+    orc.e_on_batch(s0, s1, gmm, Fm)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "sessions/s (= i-vectors/s)", "cores": _host_threads(), "kind": "port",
+            "sample": "oracle (NumPy/SciPy f64) e_on_batch, C=%d D=%d R=%d, %d sessions, %.1f s" % (C, D, R, n, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -418,6 +468,11 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(C, D)
+        # the same host cores on the other two units of the metric (bounded samples, ~10 s each)
+        if "bw_stats" in result:
+            result["bw_stats"]["cpu_baseline"] = cpu_baseline_bw(2048, D)
+        if "tv" in result:
+            result["tv"]["cpu_baseline"] = cpu_baseline_tv(2048, D, 400)
 
     if rank == 0:
         print(json.dumps(result))
