@@ -25,7 +25,7 @@
 
 #define FEAT_L 256     // frames per chunk
 #define FEAT_H 6       // frames of history a chunk re-walks (two 7-tap windows)
-#define FEAT_PF 8      // frames a lane loads ahead of the one it is working on
+#define FEAT_PF 7      // frames a lane loads ahead of the one it is working on (= one turn of the 7-deep rings)
 
 struct FeatFilt {
     double b[5];    // RASTA numerator
@@ -184,10 +184,56 @@ __global__ __launch_bounds__(256) void k_feat_carry(const void *__restrict__ X, 
     E[item * D0 + c] = y;
 }
 
+// One frame step at ring position U (compile-time).  The 7-deep rings of x, y and delta are indexed with constants
+// (a block of the frame loop is exactly 7 steps, so ring position = step within the block): no value is ever
+// moved between registers.  i = frame index relative to the start of the walk (32-bit).
+template <int NDELTA, int RASTA, int U>
+struct FeatStep {
+    static constexpr int LA = 3 * NDELTA;
+    static constexpr int at(int back) { return ((U - back) % 7 + 7) % 7; }
+
+    __device__ __forceinline__ static void run(int i, int i4, int iT, int itd0, const FeatFilt &ff, double x,
+                                               double (&xr)[7], double (&yr)[7], double (&dr)[7], double &yprev,
+                                               double (&v)[3])
+    {
+        double y;
+        if constexpr (RASTA != 0) {
+            xr[U] = x;
+            // normfeat.py:64-72: frames 0..3 only prime the FIR state; the pole starts at frame 4
+            y = ff.b[0] * xr[at(0)] + ff.b[1] * xr[at(1)] + ff.b[2] * xr[at(2)] + ff.b[3] * xr[at(3)] + ff.b[4] * xr[at(4)]
+                + ff.pole * yprev;
+            y = (i >= i4 && i < iT) ? y : 0.0;
+            yprev = y;
+        } else {
+            y = (i < iT) ? x : 0.0;
+        }
+        if constexpr (NDELTA == 0) {
+            v[0] = y;
+        } else {
+            yr[U] = y;
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) a += ff.f[k] * yr[at(k)];
+            // features.py:159,167: the convolution is stored in a float32 array; zero outside the session
+            dr[U] = (i >= itd0 && i < iT + 3) ? (double)(float)a : 0.0;      // delta of frame i - 3
+            v[0] = yr[at(LA)];
+            v[1] = dr[at(LA - 3)];
+            if constexpr (NDELTA == 2) {
+                double a2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) a2 += ff.f[k] * dr[at(k)];
+                v[2] = (double)(float)a2;
+            }
+        }
+    }
+};
+
 // MODE 0: per-chunk statistics (n, mean, M2 per output column).  MODE 1: write.
-// The frame loop is kept free of divergent branches (every lane of a wave walks another chunk): loads are made
-// unconditional by clamping the frame index, every "outside the session" case is a select, and the walk is cut
-// into a warm-up that emits nothing and a main loop that emits every frame.
+// The frame loop is kept free of divergent work (every lane of a wave walks another chunk): loads are made
+// unconditional by clamping the frame index and every "outside the session" case is a select.  It runs in blocks of
+// FEAT_PF = 7 frames: the loads of the next block are issued before the current block is processed (a lane's own
+// chain of dependent steps would otherwise expose the memory latency once per frame), and 7 steps per block make
+// the ring positions compile-time constants.
 template <int NDELTA, int RASTA, int MODE, int IN64, int OUT64>
 __global__ __launch_bounds__(256) void k_feat_walk(
     const void *__restrict__ X, long ldx, const int *__restrict__ cols,
@@ -197,6 +243,7 @@ __global__ __launch_bounds__(256) void k_feat_walk(
     int norm, const double *__restrict__ mu, const double *__restrict__ isd, long stat_stride,   // MODE 1 in
     const int64_t *__restrict__ row_base, int keep_all, void *__restrict__ out, uint8_t *__restrict__ lab_out)
 {
+    static_assert(FEAT_PF == 7, "a block of the frame loop must be one turn of the 7-deep rings");
     constexpr int LA = 3 * NDELTA;          // frames of look-ahead before a row is complete
     constexpr int NO = NDELTA + 1;          // output blocks: [static | delta | double delta]
     constexpr int XB = IN64 ? 8 : 4, OB = OUT64 ? 8 : 4;
@@ -210,21 +257,32 @@ __global__ __launch_bounds__(256) void k_feat_walk(
     const int Dout = NO * D0;
     const long T = it.T, base = it.base, n0 = it.n0;
     const long w0 = feat_b(it.j);           // the walk starts FEAT_H frames before the chunk
-    const char *xcol = static_cast<const char *>(X) + (base * ldx + col) * XB;
-    const long xstep = ldx * XB;
-    auto loadx = [&](long n) -> double {
-        const char *p = xcol + (n < T ? n : T - 1) * xstep;
+    // 32-bit indices relative to w0: frame n = w0 + i
+    const long rest = T - w0;
+    const int iT = (int)(rest < (1L << 30) ? rest : (1L << 30));     // n < T       <=>  i < iT
+    const int i4 = (w0 == 0) ? 4 : 0;                                // n >= 4      <=>  i >= i4   (w0 = 0 or >= FEAT_L - 6)
+    const int itd0 = (w0 == 0) ? 3 : 0;                              // n - 3 >= 0  <=>  i >= itd0
+    const int i_emit = (int)(n0 - w0) + LA, i_end = (int)(it.n1 - w0) + LA;
+    const char *xw0 = static_cast<const char *>(X) + ((base + w0) * ldx + col) * XB;
+    const unsigned xstep = (unsigned)(ldx * XB);
+    auto loadx = [&](int i) -> double {
+        const int ii = i < iT ? i : iT - 1;                          // clamped: always a legal address (iT >= 1)
+        const char *p = xw0 + (unsigned long)(unsigned)ii * xstep;
         return IN64 ? *reinterpret_cast<const double *>(p) : (double)*reinterpret_cast<const float *>(p);
     };
 
-    double xw[5] = {0, 0, 0, 0, 0};         // x[n-4 .. n]
-    double yw[7] = {0, 0, 0, 0, 0, 0, 0};   // y[n-6 .. n]
-    double dw[7] = {0, 0, 0, 0, 0, 0, 0};   // delta[n-9 .. n-3]
+    double xr[7] = {0, 0, 0, 0, 0, 0, 0};   // rings: slot (i % 7) holds x[i], y[i]; dr: delta[i - 3]
+    double yr[7] = {0, 0, 0, 0, 0, 0, 0};
+    double dr[7] = {0, 0, 0, 0, 0, 0, 0};
     double yprev = 0.0;
     if constexpr (RASTA != 0) {
         if (it.j > 0) {
+            // x[w0 - k] sits k slots behind slot 0 (w0 >= FEAT_L - FEAT_H > 4 here)
 #pragma unroll
-            for (int k = 1; k <= 4; ++k) xw[5 - k] = (w0 - k >= 0) ? loadx(w0 - k) : 0.0;
+            for (int k = 1; k <= 4; ++k) {
+                const char *p = xw0 - (long)k * xstep;
+                xr[7 - k] = IN64 ? *reinterpret_cast<const double *>(p) : (double)*reinterpret_cast<const float *>(p);
+            }
             // state of the pole at frame w0 - 1: the last three intervals (0.94^768 < 1e-20)
             yprev = E[(item - 1) * D0 + c];
             if (it.j >= 2) {
@@ -235,82 +293,53 @@ __global__ __launch_bounds__(256) void k_feat_walk(
             }
         }
     }
-
-    // one frame step: consumes frame n, leaves the completed row of frame n - LA in v
-    auto step = [&](long n, double x, double (&v)[3]) {
-        double y;
-        if constexpr (RASTA != 0) {
-            xw[0] = xw[1]; xw[1] = xw[2]; xw[2] = xw[3]; xw[3] = xw[4]; xw[4] = x;
-            // normfeat.py:64-72: frames 0..3 only prime the FIR state; the pole starts at frame 4
-            y = ff.b[0] * xw[4] + ff.b[1] * xw[3] + ff.b[2] * xw[2] + ff.b[3] * xw[1] + ff.b[4] * xw[0] + ff.pole * yprev;
-            y = (n >= 4 && n < T) ? y : 0.0;
-            yprev = y;
-        } else {
-            y = (n < T) ? x : 0.0;
-        }
-        if constexpr (NDELTA == 0) {
-            v[0] = y;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) yw[k] = yw[k + 1];
-            yw[6] = y;
-            double a = 0.0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) a += ff.f[k] * yw[6 - k];
-            const long td = n - 3;
-            // features.py:159,167: the convolution is stored in a float32 array; zero outside the session
-            const double d = (td >= 0 && td < T) ? (double)(float)a : 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) dw[k] = dw[k + 1];
-            dw[6] = d;
-            v[0] = yw[6 - LA];
-            v[1] = dw[6 - (LA - 3)];
-            if constexpr (NDELTA == 2) {
-                double a2 = 0.0;
-#pragma unroll
-                for (int k = 0; k < 7; ++k) a2 += ff.f[k] * dw[6 - k];
-                v[2] = (double)(float)a2;
-            }
-        }
+    // label of the row completed at step i (frame w0 + i - LA), with the RASTA fix of the first two frames
+    const uint8_t *labw = lab ? lab + base + w0 : nullptr;
+    const int lfix = (int)((T > 2 ? 2 : T - 1));
+    auto label_at = [&](int i) -> bool {
+        if (!labw) return true;
+        int t = i - LA;
+        if (RASTA != 0 && w0 == 0 && t < 2) t = lfix;
+        return labw[t] != 0;
     };
 
-    // The frame loop runs in blocks of FEAT_PF frames: the loads of the next block are issued before the current
-    // block is processed, so every lane keeps FEAT_PF loads in flight (a lane's own chain of dependent steps would
-    // otherwise expose the full HBM latency once per frame).  Frames before n0 + LA only fill the windows.
     double v[3] = {0.0, 0.0, 0.0};
-    const long n_emit = n0 + LA, n_end = it.n1 + LA;
     double xq[FEAT_PF], xn[FEAT_PF];
 #pragma unroll
-    for (int u = 0; u < FEAT_PF; ++u) xq[u] = loadx(w0 + u);
+    for (int u = 0; u < FEAT_PF; ++u) xq[u] = loadx(u);
+
+#define SKM_FEAT_BLOCK(BODY)                                                                          \
+    for (int ib = 0; ib < i_end; ib += FEAT_PF) {                                                     \
+        _Pragma("unroll") for (int u = 0; u < FEAT_PF; ++u) xn[u] = loadx(ib + FEAT_PF + u);          \
+        SKM_FEAT_ONE(0, BODY) SKM_FEAT_ONE(1, BODY) SKM_FEAT_ONE(2, BODY) SKM_FEAT_ONE(3, BODY)       \
+        SKM_FEAT_ONE(4, BODY) SKM_FEAT_ONE(5, BODY) SKM_FEAT_ONE(6, BODY)                             \
+        _Pragma("unroll") for (int u = 0; u < FEAT_PF; ++u) xq[u] = xn[u];                            \
+    }
+#define SKM_FEAT_ONE(U, BODY)                                                                         \
+    {                                                                                                 \
+        const int i = ib + U;                                                                         \
+        if (i < i_end) {                                                                              \
+            FeatStep<NDELTA, RASTA, U>::run(i, i4, iT, itd0, ff, xq[U], xr, yr, dr, yprev, v);        \
+            BODY                                                                                      \
+        }                                                                                             \
+    }
 
     if constexpr (MODE == 0) {
         double sh[NO], m1[NO], m2[NO];      // sums of (v - shift), (v - shift)^2 over the labelled frames
 #pragma unroll
         for (int k = 0; k < NO; ++k) sh[k] = m1[k] = m2[k] = 0.0;
-        long nlab = 0;
-        for (long nb = w0; nb < n_end; nb += FEAT_PF) {
-#pragma unroll
-            for (int u = 0; u < FEAT_PF; ++u) xn[u] = loadx(nb + FEAT_PF + u);
-#pragma unroll
-            for (int u = 0; u < FEAT_PF; ++u) {
-                const long n = nb + u;
-                if (n < n_end) {
-                    step(n, xq[u], v);
-                    const bool on = n >= n_emit && feat_label(lab, base, n >= n_emit ? n - LA : n0, T, RASTA);
-                    const bool first = on && nlab == 0;
-#pragma unroll
-                    for (int k = 0; k < NO; ++k) {
-                        sh[k] = first ? v[k] : sh[k];      // shift = the chunk's first labelled value
-                        const double dd = on ? v[k] - sh[k] : 0.0;
-                        m1[k] += dd;
-                        m2[k] += dd * dd;
-                    }
-                    nlab += on ? 1 : 0;
-                }
+        int nlab = 0;
+        SKM_FEAT_BLOCK({
+            const bool on = i >= i_emit && label_at(i >= i_emit ? i : i_emit);
+            const bool first = on && nlab == 0;
+            _Pragma("unroll") for (int k = 0; k < NO; ++k) {
+                sh[k] = first ? v[k] : sh[k];              /* shift = the chunk's first labelled value */
+                const double dd = on ? v[k] - sh[k] : 0.0;
+                m1[k] += dd;
+                m2[k] += dd * dd;
             }
-#pragma unroll
-            for (int u = 0; u < FEAT_PF; ++u) xq[u] = xn[u];
-        }
+            nlab += on ? 1 : 0;
+        })
         if (c == 0) part_n[item] = nlab;
 #pragma unroll
         for (int k = 0; k < NO; ++k) {
@@ -334,34 +363,24 @@ __global__ __launch_bounds__(256) void k_feat_walk(
         long orow = keep_all ? (base - seg_off[0]) + n0 : row_base[item];
         char *op = static_cast<char *>(out) + (orow * Dout + c) * OB;
         const long ostep = (long)Dout * OB, oblk = (long)D0 * OB;
-        for (long nb = w0; nb < n_end; nb += FEAT_PF) {
-#pragma unroll
-            for (int u = 0; u < FEAT_PF; ++u) xn[u] = loadx(nb + FEAT_PF + u);
-#pragma unroll
-            for (int u = 0; u < FEAT_PF; ++u) {
-                const long n = nb + u;
-                if (n < n_end) {
-                    step(n, xq[u], v);
-                    if (n >= n_emit) {
-                        const bool on = feat_label(lab, base, n - LA, T, RASTA);
-                        if (keep_all || on) {
-#pragma unroll
-                            for (int k = 0; k < NO; ++k) {
-                                const double o = (v[k] - cm[k]) * ci[k];
-                                if constexpr (OUT64 != 0) *reinterpret_cast<double *>(op + k * oblk) = o;
-                                else *reinterpret_cast<float *>(op + k * oblk) = (float)o;
-                            }
-                            if (c == 0 && lab_out) lab_out[orow] = on ? 1 : 0;
-                            op += ostep;
-                            ++orow;
-                        }
+        SKM_FEAT_BLOCK({
+            if (i >= i_emit) {
+                const bool on = label_at(i);
+                if (keep_all || on) {
+                    _Pragma("unroll") for (int k = 0; k < NO; ++k) {
+                        const double o = (v[k] - cm[k]) * ci[k];
+                        if constexpr (OUT64 != 0) *reinterpret_cast<double *>(op + k * oblk) = o;
+                        else *reinterpret_cast<float *>(op + k * oblk) = (float)o;
                     }
+                    if (c == 0 && lab_out) lab_out[orow] = on ? 1 : 0;
+                    op += ostep;
+                    ++orow;
                 }
             }
-#pragma unroll
-            for (int u = 0; u < FEAT_PF; ++u) xq[u] = xn[u];
-        }
+        })
     }
+#undef SKM_FEAT_ONE
+#undef SKM_FEAT_BLOCK
 }
 
 // Per session and output column: merge the chunks' (n, mean, M2) in chunk order, emit mean and 1/std.
