@@ -64,16 +64,12 @@ def random_ubm(sk, C, D, seed=7):
     return m
 
 
-def em_iteration(ubm, accum, X_dev):
-    """Body of the EM_split loop (mixture.py:686-710) on frames resident in HBM."""
-    accum._reset()
-    N, F, S, l = ubm._global_stats(X_dev)
-    accum.w += N
-    accum.mu += F
-    accum.invcov += S
-    llk = l / np.sum(accum.w)
-    ubm._maximization(accum)
-    return llk
+def em_iterations(ubm, X_dev, n):
+    """n passes of the body of the EM_split loop (mixture.py:686-710) on frames resident in HBM, exactly as
+    Mixture.EM_split runs a stage: per iteration the E-step, the all-reduce of the packed statistics and the
+    M-step + variance control + re-pack of the model on the device; at the end of the stage the parameters and the
+    per-iteration mean log-likelihoods come back to the host (a full sync).  Returns the last log-likelihood."""
+    return ubm._em_iterations_device(X_dev, n)[-1]
 
 
 def cpu_baseline(C, D, seconds_target=15.0):
@@ -188,8 +184,6 @@ def main():
 
     X = synth_frames_device(torch, T, D, seed=1234 + rank, device=dev)
     ubm = random_ubm(sk, C, D)
-    import copy
-    accum = copy.deepcopy(ubm)
 
     def sync():
         if world > 1:
@@ -210,9 +204,9 @@ def main():
             dt = float(tt.item())
         return dt, r
 
-    for _ in range(args.warmup):
-        em_iteration(ubm, accum, X)
-    dt, llk = timed(lambda: em_iteration(ubm, accum, X), args.steps)
+    if args.warmup > 0:
+        em_iterations(ubm, X, args.warmup)
+    dt, llk = timed(lambda: em_iterations(ubm, X, args.steps), 1)
     ms_per_step = 1e3 * dt / args.steps
     value = world * T * args.steps / dt
 
@@ -231,8 +225,7 @@ def main():
     # it (the iteration contains the all-reduce); rank 0 reports its own kernels.
     eng.profile(True)
     nprof = 3
-    for _ in range(nprof):
-        em_iteration(ubm, accum, X)
+    em_iterations(ubm, X, nprof)
     torch.cuda.synchronize()
     prof = eng.profile_read()
     eng.profile(False)
@@ -244,13 +237,13 @@ def main():
             # single-sweep kernel (C <= 512): the whole E-step is one kernel, all 8*D*C*T flops are its own
             dom = single[0]
             t_dom, flop_dom, issued = kt[dom], flop_path, (4.0 * D + 4.0 * 64) * C * T
-            t_path = sum(kt.get(k, 0.0) for k in (dom, "k_reduce_slabs"))
+            t_path = sum(kt.get(k, 0.0) for k in (dom, "k_reduce_slabs", "k_mstep_pack"))
         else:
             # two sweeps: the statistics GEMM gamma^T [x, x^2] is the algorithmic work of k_stats_em; the
             # logits it recomputes are NOT counted
             dom, t_dom, flop_dom = "k_stats_em", kt.get("k_stats_em", float("nan")), 4.0 * D * C * T
             issued = (8.0 * D + 4.0 * 64) * C * T
-            t_path = sum(kt.get(k, 0.0) for k in ("k_lse_partial", "k_lse_combine", "k_stats_em", "k_reduce_slabs"))
+            t_path = sum(kt.get(k, 0.0) for k in ("k_lse_partial", "k_lse_combine", "k_stats_em", "k_reduce_slabs", "k_mstep_pack"))
         ach = flop_dom / (t_dom * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach,
                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
@@ -310,11 +303,10 @@ def main():
         # ---- EM iteration at the target size (BASELINE configs[2] per-GPU shape, fewer frames): C=2048
         Ce, Te = 2048, min(T, 4_000_000)
         ubm_e = random_ubm(sk, Ce, D, seed=11)
-        acc_e = copy.deepcopy(ubm_e)
         Xe = X[:Te]
-        em_iteration(ubm_e, acc_e, Xe)
+        em_iterations(ubm_e, Xe, 1)
         eng.profile(True)
-        dte, _ = timed(lambda: em_iteration(ubm_e, acc_e, Xe), 2)
+        dte, _ = timed(lambda: em_iterations(ubm_e, Xe, 2), 1)
         dte /= 2
         prof = eng.profile_read()
         eng.profile(False)
@@ -328,7 +320,7 @@ def main():
                               "roofline_path": {"bound": "mfma", "achieved": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12,
                                                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                                 "frac": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
-        del ubm_e, acc_e, Xe
+        del ubm_e, Xe
 
     if "scoring" in legs:
         # ---- GMM-UBM LLR scoring (next row after the statistics path, gmm_scoring.py:56-119): every enrolled model

@@ -63,6 +63,19 @@ size_t skm_gmm_packed_bytes(int C, int D);
 int skm_gmm_pack(void *ctx, const double *w_host, const double *mu_host, const double *invcov_host,
                  int C, int D, void *packed_dev, void *stream);
 
+/* M-step and re-pack on the device, so that an EM iteration needs no host round trip:
+ *   stats_dev        [ N | F | S | llk ] as skm_gmm_estep leaves it (after the all-reduce in a multi-GPU run)
+ *   cov_var_ctl_dev  C*D float64, the variance-control reference of the model (sidekit/mixture.py:636-640)
+ *   params_dev       out: [ w (C) | mu (C*D) | invcov (C*D) | sum N ] float64
+ *   packed_dev       out: the image skm_gmm_pack would build from those parameters
+ *   llk_mean_dev     out (optional): llk / sum N, the value EM_split appends per iteration (mixture.py:706)
+ * w = N / sum N, mu = F / N, cov = S / N - mu^2 clamped to [floor_cov, ceil_cov] * cov_var_ctl with the reference's
+ * inclusive comparisons, invcov = 1 / cov.  Replaces Mixture._maximization + variance_control + _compute_all
+ * (sidekit/mixture.py:590-611, 489-506, 382-396) inside the EM loop; float64 throughout. */
+int skm_gmm_mstep_pack(void *ctx, const double *stats_dev, const double *cov_var_ctl_dev, int C, int D,
+                       double ceil_cov, double floor_cov, double *params_dev, void *packed_dev,
+                       double *llk_mean_dev, void *stream);
+
 /* Workspace bytes for skm_gmm_estep / skm_gmm_loglik / skm_bw_stats over T frames. */
 size_t skm_gmm_workspace_bytes(void *ctx, long T, int C, int D);
 

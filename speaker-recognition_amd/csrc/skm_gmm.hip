@@ -2401,6 +2401,117 @@ extern "C" int skm_gmm_pack(void *ctx, const double *w, const double *mu, const 
     return SKM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// M-step + re-pack on the device: the statistics of an EM iteration never visit the host.
+//   params = [ w (C) | mu (C*D) | invcov (C*D) | sum N (1) ]  float64
+// ------------------------------------------------------------------------------------------------
+// sum of N[C] in a fixed order (one workgroup), and the iteration's mean log-likelihood llk / sum N
+__global__ __launch_bounds__(256) void k_mstep_sum(const double *__restrict__ stats, int C, int D, double *__restrict__ params,
+                                                    double *__restrict__ llk_mean)
+{
+    __shared__ double part[256];
+    double s = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) s += stats[c];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        params[(size_t)C + 2 * (size_t)C * D] = part[0];
+        if (llk_mean) *llk_mean = stats[(size_t)C + 2 * (size_t)C * D] / part[0];
+    }
+}
+
+// w = N / sum N, mu = F / N, cov = S / N - mu^2 clamped to [floor, ceil] * ctl (inclusive), invcov = 1 / cov
+// (Mixture._maximization + variance_control, sidekit/mixture.py:590-611, 489-506)
+__global__ __launch_bounds__(256) void k_mstep_params(const double *__restrict__ stats, const double *__restrict__ ctl,
+                                                       int C, int D, double ceil_cov, double floor_cov,
+                                                       double *__restrict__ params)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)C * D) return;
+    const int c = (int)(e / D);
+    const double n = stats[c], sumN = params[(size_t)C + 2 * (size_t)C * D];
+    if (e % D == 0) params[c] = n / sumN;
+    const double m = stats[(size_t)C + e] / n;
+    double cov = stats[(size_t)C + (size_t)C * D + e] / n - m * m;
+    const double fl = floor_cov * ctl[e], ce = ceil_cov * ctl[e];
+    if (cov <= fl) cov = fl;
+    if (cov >= ce) cov = ce;
+    params[(size_t)C + e] = m;
+    params[(size_t)C + (size_t)C * D + e] = 1.0 / cov;
+}
+
+// the packed image of skm_gmm_pack, from parameters in device memory
+__global__ __launch_bounds__(256) void k_pack_w(const double *__restrict__ params, int C, int D, int CTpad, int NCH, int NP,
+                                                 float *__restrict__ wp)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;      // ((tile * NCH + grp) * 64 + lane) * 4 + i
+    if (e >= (long)CTpad * NCH * 256) return;
+    const int i = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    const long tg = e >> 8;
+    const int grp = (int)(tg % NCH), tile = (int)(tg / NCH);
+    const int comp = tile * 32 + (lane & 31), h = lane >> 5;
+    int d, kind;
+    if (grp < 2 * NP) {
+        d = 8 * (grp >> 1) + 4 * h + i;
+        kind = grp & 1;
+    } else {
+        d = 8 * NP + i;
+        kind = h;
+    }
+    double v = 0.0;
+    if (comp < C && d < D) {
+        const double icv = params[(size_t)C + (size_t)C * D + (size_t)comp * D + d];
+        v = kind ? (-0.5 * 1.4426950408889634074 * icv)
+                 : (1.4426950408889634074 * params[(size_t)C + (size_t)comp * D + d] * icv);
+    }
+    wp[e] = (float)v;
+}
+
+__global__ __launch_bounds__(256) void k_pack_kc(const double *__restrict__ params, int C, int D, int ncomp,
+                                                  float *__restrict__ kc)
+{
+    const int comp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (comp >= ncomp) return;
+    double v = -1.0e30;
+    if (comp < C) {
+        const double *mu = params + C + (size_t)comp * D, *ic = params + C + (size_t)C * D + (size_t)comp * D;
+        double logdet_inv = 0.0, quad = 0.0;
+        for (int d = 0; d < D; ++d) {
+            logdet_inv += log(ic[d]);
+            quad += mu[d] * mu[d] * ic[d];
+        }
+        v = 1.4426950408889634074 * (log(params[comp]) + 0.5 * logdet_inv - 0.5 * D * log(2.0 * M_PI) - 0.5 * quad);
+        if (!(v > -1.0e30)) v = -1.0e30;  // w = 0 or NaN: component never wins
+    }
+    kc[comp] = (float)v;
+}
+
+extern "C" int skm_gmm_mstep_pack(void *ctx_, const double *stats_dev, const double *cov_var_ctl_dev, int C, int D,
+                                  double ceil_cov, double floor_cov, double *params_dev, void *packed_dev,
+                                  double *llk_mean_dev, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && stats_dev && cov_var_ctl_dev && params_dev && packed_dev, "skm_gmm_mstep_pack: NULL argument");
+    SKM_REQUIRE(C > 0 && D > 0, "skm_gmm_mstep_pack: bad shape C=%d D=%d", C, D);
+    hipStream_t st = (hipStream_t)stream;
+    const GmmGeom g = skm_geom(C, D);
+    float *wp = static_cast<float *>(packed_dev);
+    float *kc = wp + (size_t)g.CTpad * g.NCH * 256;
+    SkmProfScope ps(ctx, "k_mstep_pack", st);
+    hipLaunchKernelGGL(k_mstep_sum, dim3(1), dim3(256), 0, st, stats_dev, C, D, params_dev, llk_mean_dev);
+    hipLaunchKernelGGL(k_mstep_params, dim3((unsigned)(((long)C * D + 255) / 256)), dim3(256), 0, st, stats_dev,
+                       cov_var_ctl_dev, C, D, ceil_cov, floor_cov, params_dev);
+    hipLaunchKernelGGL(k_pack_w, dim3((unsigned)(((long)g.CTpad * g.NCH * 256 + 255) / 256)), dim3(256), 0, st, params_dev, C, D,
+                       g.CTpad, g.NCH, g.NP, wp);
+    hipLaunchKernelGGL(k_pack_kc, dim3((g.CTpad * 32 + 255) / 256), dim3(256), 0, st, params_dev, C, D, g.CTpad * 32, kc);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
 // Launch plan shared by every entry point.
 struct Plan {
     GmmGeom g;

@@ -30,6 +30,8 @@ SIGNATURES = {
     "skm_prof_read": (_c_long, [_c_void_p, ctypes.c_char_p, _c_size_t]),
     "skm_gmm_packed_bytes": (_c_size_t, [_c_int, _c_int]),
     "skm_gmm_pack": (_c_int, [_c_void_p, _dp, _dp, _dp, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "skm_gmm_mstep_pack": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, ctypes.c_double, ctypes.c_double,
+                                    _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "skm_gmm_workspace_bytes": (_c_size_t, [_c_void_p, _c_long, _c_int, _c_int]),
     "skm_gmm_estep": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                                _c_void_p, _c_size_t, _c_void_p]),
@@ -167,6 +169,21 @@ class HipEngine(object):
                                           invcov.ctypes.data_as(_dp), C, D, _c_void_p(packed.data_ptr()),
                                           self._stream()))
         return PackedGMM(packed, C, D)
+
+    def mstep_pack(self, stats, cov_var_ctl, gmm, ceil_cov, floor_cov, params=None, llk_mean=None):
+        """M-step + re-pack on the device (skm_gmm_mstep_pack): `gmm` (a PackedGMM) is overwritten with the new
+        model, `params` = [w | mu | invcov | sum N] float64 device tensor; `llk_mean` a 1-element float64 view."""
+        torch = self.torch
+        C, D = gmm.C, gmm.D
+        assert stats.dtype == torch.float64 and stats.numel() == 2 * C * D + C + 1 and stats.is_contiguous()
+        assert cov_var_ctl.dtype == torch.float64 and cov_var_ctl.numel() == C * D and cov_var_ctl.is_contiguous()
+        if params is None:
+            params = torch.empty(2 * C * D + C + 1, dtype=torch.float64, device=self.device)
+        self._check(self.lib.skm_gmm_mstep_pack(
+            self.ctx, _c_void_p(stats.data_ptr()), _c_void_p(cov_var_ctl.data_ptr()), C, D, float(ceil_cov),
+            float(floor_cov), _c_void_p(params.data_ptr()), _c_void_p(gmm.packed.data_ptr()),
+            _c_void_p(llk_mean.data_ptr()) if llk_mean is not None else None, self._stream()))
+        return params
 
     def estep(self, X, gmm, out=None, accumulate=False):
         """[N | F | S | llk] float64 device tensor for the frames X (T x D float32 device tensor)."""

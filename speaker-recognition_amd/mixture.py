@@ -311,16 +311,30 @@ class Mixture(object):
                 ext = ".h5" if _has_h5py() else ".npz"
                 self.write('{}_{}g{}'.format(output_file_name, self.get_distrib_nb(), ext), prefix='')
             self._split_ditribution()
-            accum = copy.deepcopy(self)
-            for i in range(it):
-                accum._reset()
-                N, F, S, l = self._global_stats(X_dev)
-                accum.w += N
-                accum.mu += F
-                accum.invcov += S
-                llk.append(l / np.sum(accum.w))
-                self._maximization(accum, ceil_cov=ceil_cov, floor_cov=floor_cov)
+            llk.extend(self._em_iterations_device(X_dev, it, ceil_cov, floor_cov))
         return llk
+
+    def _em_iterations_device(self, X_dev, it, ceil_cov=10, floor_cov=1e-2):
+        """`it` EM iterations of the loop body mixture.py:686-710 with the model resident on the GPU: E-step,
+        all-reduce of the packed statistics, M-step + variance control + re-pack (skm_gmm_mstep_pack) -- no host
+        round trip inside the loop.  The parameters and the per-iteration mean log-likelihoods come back once."""
+        eng = self.engine
+        torch = eng.torch
+        C, D = self.distrib_nb(), self.dim()
+        packed = self._pack()
+        ctl = torch.from_numpy(np.ascontiguousarray(self.cov_var_ctl, dtype=np.float64)).to(eng.device)
+        llk_dev = torch.empty(it, dtype=torch.float64, device=eng.device)
+        params = stats = None
+        for i in range(it):
+            stats = eng.estep(X_dev, packed, out=stats)
+            dist.allreduce_sum_(stats)
+            params = eng.mstep_pack(stats, ctl, packed, ceil_cov, floor_cov, params=params, llk_mean=llk_dev[i:i + 1])
+        flat = eng.to_host(params)
+        self.w = flat[:C].copy()
+        self.mu = flat[C:C + C * D].reshape(C, D).copy()
+        self.invcov = flat[C + C * D:C + 2 * C * D].reshape(C, D).copy()
+        self._compute_all()
+        return [float(v) for v in eng.to_host(llk_dev)]
 
     def EM_uniform(self, cep, distrib_nb, iteration_min=3, iteration_max=10, llk_gain=0.01, do_init=True):
         """EM from a uniform-slice start with an early stop on the gain (mixture.py:735-794)."""

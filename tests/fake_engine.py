@@ -31,6 +31,20 @@ class OracleEngine(object):
     def pack(self, w, mu, invcov):
         return _Packed(w, mu, invcov)
 
+    def mstep_pack(self, stats, cov_var_ctl, gmm, ceil_cov, floor_cov, params=None, llk_mean=None):
+        """Oracle M-step (sidekit/mixture.py:590-611) on the packed statistics; `gmm` is updated in place."""
+        C, D = gmm.C, gmm.D
+        flat = stats.numpy()
+        N = flat[:C].copy()
+        F = flat[C:C + C * D].reshape(C, D)
+        S = flat[C + C * D:C + 2 * C * D].reshape(C, D)
+        g = gmm.gmm
+        g.cov_var_ctl = cov_var_ctl.numpy().reshape(C, D)
+        orc.maximization(g, N, F, S, ceil_cov=ceil_cov, floor_cov=floor_cov)
+        if llk_mean is not None:
+            llk_mean[0] = flat[-1] / N.sum()
+        return torch.from_numpy(np.concatenate([g.w, g.mu.ravel(), g.invcov.ravel(), [N.sum()]]))
+
     def estep(self, X, gmm, out=None, accumulate=False):
         N, F, S, llk = orc.expectation(gmm.gmm, X.numpy().astype(np.float64))
         flat = torch.from_numpy(np.concatenate([N, F.ravel(), S.ravel(), [llk]]))

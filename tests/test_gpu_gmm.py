@@ -444,3 +444,78 @@ def test_gmm_scoring_vs_oracle_c512(sk):
                           {s: np.asarray(f, dtype=np.float64) for s, f in feats.items()})
     assert np.abs(sc.scoremat - ref).max() < 2e-4, np.abs(sc.scoremat - ref).max()
     assert (sc.scoremat[~sc.scoremask] == 0).all()
+
+
+@pytest.mark.parametrize("C,D", [(8, 6), (40, 13), (512, 60), (96, 20)])
+def test_device_mstep_and_repack_equal_host_path(sk, eng, C, D):
+    """skm_gmm_mstep_pack (M-step + variance control + re-pack in HBM) against the host float64 M-step of the
+    drop-in (mixture.py:590-611) followed by skm_gmm_pack: parameters to 1e-14, the packed float32 image
+    bit-identical up to one float32 ulp of the log-domain constants, including a component that hits the
+    variance floor, one that hits the ceiling and an empty one (N = 0 -> NaN, as NumPy gives)."""
+    import copy
+    torch = eng.torch
+    rs = np.random.RandomState(C + D)
+    gmm = orc.random_gmm(C, D, seed=3)
+    cep = orc.synth_frames(4000, dim=D, clusters=max(2, C // 4), seed=5, dtype=np.float64)
+    N, F, S, llk = orc.expectation(gmm, cep)
+    ctl = 1.0 / gmm.invcov
+    ctl[0] *= 1e4                                 # floor above the estimate: component 0 is floored
+    ctl[1] *= 1e-4                                # ceiling below the estimate: component 1 is capped
+    stats = np.concatenate([N, F.ravel(), S.ravel(), [llk]])
+    m = sk.Mixture()
+    m.w, m.mu, m.invcov = gmm.w.copy(), gmm.mu.copy(), gmm.invcov.copy()
+    m.cov_var_ctl = ctl.copy()
+    m._compute_all()
+    accum = copy.deepcopy(m)
+    accum.w, accum.mu, accum.invcov = N.copy(), F.copy(), S.copy()
+    host = copy.deepcopy(m)
+    host._maximization(accum, ceil_cov=10, floor_cov=1e-2)
+    assert np.any(1.0 / host.invcov[0] == 1e-2 * ctl[0]) and np.any(1.0 / host.invcov[1] == 10 * ctl[1])
+
+    packed = eng.pack(m.w, m.mu, m.invcov)
+    llk_dev = torch.zeros(1, dtype=torch.float64, device=eng.device)
+    params = eng.mstep_pack(torch.from_numpy(stats).to(eng.device), torch.from_numpy(ctl.ravel().copy()).to(eng.device),
+                            packed, 10, 1e-2, llk_mean=llk_dev)
+    flat = eng.to_host(params)
+    assert rel(flat[:C], host.w) < 1e-14
+    assert rel(flat[C:C + C * D].reshape(C, D), host.mu) < 1e-14
+    assert rel(flat[C + C * D:C + 2 * C * D].reshape(C, D), host.invcov) < 1e-14
+    assert abs(flat[-1] - N.sum()) <= 1e-12 * N.sum()
+    assert abs(float(llk_dev.item()) - llk / N.sum()) <= 1e-14 * abs(llk / N.sum())
+    ref_img = eng.pack(host.w, host.mu, host.invcov).packed.cpu().numpy().view(np.float32)
+    img = packed.packed.cpu().numpy().view(np.float32)
+    assert img.shape == ref_img.shape
+    assert np.abs(img - ref_img).max() <= 2e-7 * np.abs(ref_img[np.abs(ref_img) < 1e29]).max()
+    # the E-step on the re-packed model equals the E-step on the host-packed one
+    X = eng.upload_frames(cep)
+    a = eng.to_host(eng.estep(X, packed))
+    b = eng.to_host(eng.estep(X, eng.pack(host.w, host.mu, host.invcov)))
+    assert rel(a, b) < 1e-5
+
+
+def test_em_split_device_loop_equals_host_loop(sk, eng):
+    """EM_split with the model resident on the GPU (skm_gmm_mstep_pack in the loop) against the same schedule
+    driven through the host M-step (_global_stats + _maximization): same model, same log-likelihood trace."""
+    import copy
+    g = golden("em_split.npz")
+    chunks = {"f%d" % i: g["chunk%d" % i] for i in range(4)}
+    fs = sk.FeaturesServer(features=chunks)
+    dev = sk.Mixture()
+    llk_dev = dev.EM_split(features_server=fs, feature_list=list(chunks.keys()), distrib_nb=8, num_thread=1)
+    host = sk.Mixture()
+    X = host._init(fs, list(chunks.keys()), 1)
+    llk_host = []
+    for it in (1, 2, 2):
+        host._split_ditribution()
+        accum = copy.deepcopy(host)
+        for _ in range(it):
+            accum._reset()
+            N, F, S, l = host._global_stats(X)
+            accum.w += N
+            accum.mu += F
+            accum.invcov += S
+            llk_host.append(l / np.sum(accum.w))
+            host._maximization(accum)
+    assert rel(np.array(llk_dev), np.array(llk_host)) < 1e-9
+    assert rel(dev.w, host.w) < 1e-7 and rel(dev.mu, host.mu) < 1e-7 and rel(dev.invcov, host.invcov) < 1e-7
+    assert rel(dev.A, host.A) < 1e-7
