@@ -27,18 +27,17 @@ _NORMS = {None: 0, "cms": 1, "cmvn": 2}
 
 
 def parse_mask(mask):
-    """'[1-3,10,15-20]' -> [1, 2, 3, 10, 15, ..., 20]  (sidekit/sv_utils.py:377-394)."""
-    if not set(re.sub(r"\s", "", mask)[1:-1]).issubset(set("0123456789-,")):
-        raise Exception("Wrong mask format")
-    tmp = [k.split('-') for k in re.sub(r"[\s]", '', mask)[1:-1].split(',')]
+    """'[1-3,10,15-20]' -> [1, 2, 3, 10, 15, ..., 20]: comma-separated column indices or inclusive ranges inside
+    one pair of brackets (same grammar and errors as sidekit/sv_utils.py:377-394)."""
+    body = "".join(mask.split())[1:-1]
     indices = []
-    for seg in tmp:
-        if len(seg) == 1:
-            seg += seg
-        if len(seg) == 2:
-            indices += list(range(int(seg[0]), int(seg[1]) + 1))
-        else:
+    for item in body.split(","):
+        m = re.fullmatch(r"(\d+)(?:-(\d+))?", item)
+        if m is None:
             raise Exception("Wrong mask format")
+        first = int(m.group(1))
+        last = first if m.group(2) is None else int(m.group(2))
+        indices.extend(range(first, last + 1))
     return indices
 
 

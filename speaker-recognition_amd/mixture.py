@@ -319,21 +319,11 @@ class Mixture(object):
         all-reduce of the packed statistics, M-step + variance control + re-pack (skm_gmm_mstep_pack) -- no host
         round trip inside the loop.  The parameters and the per-iteration mean log-likelihoods come back once."""
         eng = self.engine
-        torch = eng.torch
-        C, D = self.distrib_nb(), self.dim()
-        packed = self._pack()
-        ctl = torch.from_numpy(np.ascontiguousarray(self.cov_var_ctl, dtype=np.float64)).to(eng.device)
-        llk_dev = torch.empty(it, dtype=torch.float64, device=eng.device)
-        params = stats = None
+        loop = _DeviceEM(self, X_dev, ceil_cov, floor_cov)
+        llk_dev = eng.torch.empty(it, dtype=eng.torch.float64, device=eng.device)
         for i in range(it):
-            stats = eng.estep(X_dev, packed, out=stats)
-            dist.allreduce_sum_(stats)
-            params = eng.mstep_pack(stats, ctl, packed, ceil_cov, floor_cov, params=params, llk_mean=llk_dev[i:i + 1])
-        flat = eng.to_host(params)
-        self.w = flat[:C].copy()
-        self.mu = flat[C:C + C * D].reshape(C, D).copy()
-        self.invcov = flat[C + C * D:C + 2 * C * D].reshape(C, D).copy()
-        self._compute_all()
+            loop.step(llk_mean=llk_dev[i:i + 1])
+        loop.download()
         return [float(v) for v in eng.to_host(llk_dev)]
 
     def EM_uniform(self, cep, distrib_nb, iteration_min=3, iteration_max=10, llk_gain=0.01, do_init=True):
@@ -342,26 +332,23 @@ class Mixture(object):
         n_total = cep.shape[0]
         if do_init:
             self._init_uniform(cep, distrib_nb)
-        accum = copy.deepcopy(self)
         local = cep
         if dist.is_dist():
             a, b = dist.shard_bounds(n_total)
             local = cep[a:b]
         X_dev = self._device_frames(local)
+        # the model stays on the GPU; only the summed log-likelihood (8 bytes) is read per iteration for the gain test
+        loop = _DeviceEM(self, X_dev, 10, 1e-2)
         for i in range(0, iteration_max):
-            accum._reset()
-            N, F, S, l = self._global_stats(X_dev)
-            accum.w += N
-            accum.mu += F
-            accum.invcov += S
-            llk.append(l / n_total)
-            self._maximization(accum)
+            stats = loop.step()
+            llk.append(float(self.engine.to_host(stats[-1:])[0]) / n_total)
             if i > 0:
                 gain = llk[-1] - llk[-2]
                 if gain < llk_gain and i >= iteration_min:
                     logging.debug('EM (break) distrib_nb: %d %i/%d gain: %f -- %s, %d',
                                   self.mu.shape[0], i + 1, iteration_max, gain, self.name, n_total)
                     break
+        loop.download()
         return llk
 
     def _init_uniform(self, cep, distrib_nb):
@@ -412,6 +399,40 @@ class Mixture(object):
         (statserver.py:83-95) without materialising the T x C matrix."""
         X = self._device_frames(cep)
         return self.engine.to_host(self.engine.loglik(X, self._pack())).astype(np.float64)
+
+
+
+class _DeviceEM(object):
+    """EM iterations with the model resident on the GPU (Mixture.EM_split / EM_uniform): step() = E-step over the
+    rank's frames, all-reduce of the packed statistics, M-step + variance control + re-pack on the device
+    (skm_gmm_mstep_pack); download() brings the parameters back and refreshes det / cst / A."""
+
+    def __init__(self, mixture, X_dev, ceil_cov, floor_cov):
+        eng = mixture.engine
+        self.m, self.eng, self.X = mixture, eng, X_dev
+        self.ceil, self.floor = ceil_cov, floor_cov
+        self.packed = mixture._pack()
+        self.ctl = eng.torch.from_numpy(np.ascontiguousarray(mixture.cov_var_ctl, dtype=np.float64)).to(eng.device)
+        self.params = self.stats = None
+
+    def step(self, llk_mean=None):
+        """One iteration; returns the all-reduced statistics [N | F | S | llk] it was made from (device)."""
+        self.stats = self.eng.estep(self.X, self.packed, out=self.stats)
+        dist.allreduce_sum_(self.stats)
+        self.params = self.eng.mstep_pack(self.stats, self.ctl, self.packed, self.ceil, self.floor,
+                                          params=self.params, llk_mean=llk_mean)
+        return self.stats
+
+    def download(self):
+        if self.params is None:
+            return
+        m = self.m
+        C, D = m.distrib_nb(), m.dim()
+        flat = self.eng.to_host(self.params)
+        m.w = flat[:C].copy()
+        m.mu = flat[C:C + C * D].reshape(C, D).copy()
+        m.invcov = flat[C + C * D:C + 2 * C * D].reshape(C, D).copy()
+        m._compute_all()
 
 
 def _has_h5py():
