@@ -107,7 +107,11 @@ struct TileIO {
     }
 };
 
-template <typename TI, typename TO, bool ACC64>
+// GUARD: waves test a 4-bit mask before each of their 2 x 2 MFMA blocks and skip the blocks that lie outside the
+// matrix or under the block mask.  Chosen per launch (skm_gemm_launch): it pays when edge or diagonal tiles are a
+// sizeable share of the grid (R = 400 leaves 16 valid columns in the last of its four 128-wide tiles: the aux
+// product went from 7.1 to 4.7 ms) and costs ~6 % on grids of full tiles, which keep the unguarded loop.
+template <typename TI, typename TO, bool ACC64, bool GUARD>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
 {
     typedef Mf<TI> M;
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
     __shared__ __align__(16) TI As[2][BK * LDT];
     __shared__ __align__(16) TI Bs[2][BK * LDT];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int z = blockIdx.z;
     int bx = blockIdx.x, by = blockIdx.y;
@@ -212,6 +216,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
             IO::load(rb, B, g.ldb, bkfast, bvec, n0, kt * BK, N, K, tid, g.colmap);
         }
     };
+    // which of this wave's 2 x 2 MFMA blocks produce anything that the epilogue stores (wave-uniform)
+    int need_bits = 15;
+    if (GUARD) {
+    need_bits = 0;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int bm0 = m0 + wm * 2 * TM + mi * TM, bn0 = n0 + wn * 2 * TM + ni * TM;
+            bool nd = bm0 < Mr && bn0 < N;
+            if (g.tile_mask == 1 && (bn0 + TM - 1) / g.mask_blk < bm0 / g.mask_blk) nd = false;
+            need_bits |= nd ? (1 << (mi * 2 + ni)) : 0;
+        }
+    need_bits = __builtin_amdgcn_readfirstlane(need_bits);
+    }
     load_tile(kt0);
     IO::store(ra, As[0], LDT, akfast, tid);
     IO::store(rb, Bs[0], LDT, bkfast, tid);
@@ -222,6 +241,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
         if (kt + 1 < nk) load_tile(kt + 1);
         const TI *Ac = As[cur] + wm * 2 * TM + lm;
         const TI *Bc = Bs[cur] + wn * 2 * TM + lm;
+        // a wave skips its TM x TM blocks that lie outside the matrix or under the block mask (wave-uniform bits:
+        // R = 400 leaves 16 valid columns in its last 128-wide tile)
 #pragma unroll
         for (int kk = 0; kk < BK / KS; ++kk) {
             TI a[2], b[2];
@@ -232,7 +253,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = M::mfma(a[mi], b[ni], acc[mi][ni]);
+                for (int ni = 0; ni < 2; ++ni)
+                    if (!GUARD || (need_bits & (1 << (mi * 2 + ni)))) acc[mi][ni] = M::mfma(a[mi], b[ni], acc[mi][ni]);
         }
         if (ACC64 && ++since == FOLD) {
             since = 0;
@@ -310,15 +332,29 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
              (vec_ok(g.B, g.ldb, g.sB, g.tri_ldz, g.tri_n > 0 && g.tri_blk % (16 / (int)esz) == 0, esz) ? 2 : 0);
     if (g.tri_n > 0 && g.tri_blk % (16 / (int)esz) != 0) gv.vec &= 1;
     if (g.colmap && !g.colmap_vec) gv.vec &= 1;
+    // guard the MFMA blocks when edge tiles (at least one TM-wide block of the last tile row / column is outside the
+    // matrix) or masked diagonal tiles are a sizeable share of the grid
+    const int tmb = tile / 4;
+    const int tiles_m = (g.M + tile - 1) / tile, tiles_n = (ncols + tile - 1) / tile;
+    const bool edge_m = (tiles_m * tile - g.M) >= tmb, edge_n = (tiles_n * tile - ncols) >= tmb;
+    const double share = (edge_m ? 1.0 / tiles_m : 0.0) + (edge_n ? 1.0 / tiles_n : 0.0) +
+                         (g.tile_mask == 1 ? 1.0 / (tiles_m < tiles_n ? tiles_m : tiles_n) : 0.0);
+    const bool guard = share >= 0.10 || g.tri_n > 0;
     SkmProfScope ps(ctx, tag, st);
+#define SKM_GEMM_GO(TI_, TO_, ACC_)                                                                   \
+    do {                                                                                               \
+        if (guard) hipLaunchKernelGGL((k_gemm<TI_, TO_, ACC_, true>), grid, dim3(256), 0, st, gv);     \
+        else hipLaunchKernelGGL((k_gemm<TI_, TO_, ACC_, false>), grid, dim3(256), 0, st, gv);          \
+    } while (0)
     switch (kind) {
-    case SKM_GEMM_F32_F32: hipLaunchKernelGGL((k_gemm<float, float, false>), grid, dim3(256), 0, st, gv); break;
-    case SKM_GEMM_F32_F64ACC: hipLaunchKernelGGL((k_gemm<float, double, true>), grid, dim3(256), 0, st, gv); break;
-    case SKM_GEMM_F32_F64OUT: hipLaunchKernelGGL((k_gemm<float, double, false>), grid, dim3(256), 0, st, gv); break;
-    case SKM_GEMM_F64_F64: hipLaunchKernelGGL((k_gemm<double, double, false>), grid, dim3(256), 0, st, gv); break;
-    case SKM_GEMM_F64_F32OUT: hipLaunchKernelGGL((k_gemm<double, float, false>), grid, dim3(256), 0, st, gv); break;
+    case SKM_GEMM_F32_F32: SKM_GEMM_GO(float, float, false); break;
+    case SKM_GEMM_F32_F64ACC: SKM_GEMM_GO(float, double, true); break;
+    case SKM_GEMM_F32_F64OUT: SKM_GEMM_GO(float, double, false); break;
+    case SKM_GEMM_F64_F64: SKM_GEMM_GO(double, double, false); break;
+    case SKM_GEMM_F64_F32OUT: SKM_GEMM_GO(double, float, false); break;
     default: skm_set_error("gemm(%s): unknown kind %d", tag, kind); return SKM_ERR_ARG;
     }
+#undef SKM_GEMM_GO
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }
