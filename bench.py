@@ -155,8 +155,8 @@ def main():
     ap.add_argument("--frames", type=int, default=10_000_000, help="frames per GPU")
     ap.add_argument("--comps", type=int, default=512)
     ap.add_argument("--dim", type=int, default=60)
-    ap.add_argument("--tv-sessions", type=int, default=4096)
-    ap.add_argument("--tv-batch", type=int, default=2048, help="sessions per TV E-step batch")
+    ap.add_argument("--tv-sessions", type=int, default=8192)
+    ap.add_argument("--tv-batch", type=int, default=4096, help="sessions per TV E-step batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (BW stats)")
     ap.add_argument("--legs", default="bw,em2048,scoring,feat,tv",

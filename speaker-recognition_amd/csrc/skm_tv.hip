@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void k_tv_whiten(const TS *__restrict__ stat0,
 
 // Column map of the flattened upper-block view of an R x R matrix: for row z (block b = z / 32) the logical
 // columns start(z) .. start(z) + R - 32 b - 1 map to element offsets z*R + 32 b + j.
+#define TV_CS_SPLIT 16   // session ranges of the e_hh column sums
 static inline long tv_tri_cols(int R)
 {
     long n = 0;
@@ -323,6 +324,32 @@ __global__ __launch_bounds__(256) void k_tv_solve(const double *__restrict__ Ub,
     }
 }
 
+// _R accumulator: column sums of E[nb][R*R] (float32, block-upper entries only) over the sessions of a batch.
+// Two steps without atomics: TV_CS_SPLIT session ranges -> part[split][NT] (float64), then row C of A_aug += their sum.
+__global__ __launch_bounds__(256) void k_ehh_colsum(const float *__restrict__ E, long RR, int nb, const int *__restrict__ cmap,
+                                                    int NT, double *__restrict__ part)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= NT) return;
+    const int per = (nb + TV_CS_SPLIT - 1) / TV_CS_SPLIT;
+    const int s0 = blockIdx.y * per, s1 = (s0 + per < nb) ? s0 + per : nb;
+    const float *p = E + cmap[n];
+    double acc = 0.0;
+    for (int s = s0; s < s1; ++s) acc += (double)p[(long)s * RR];
+    part[(long)blockIdx.y * NT + n] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_ehh_colsum_add(const double *__restrict__ part, const int *__restrict__ cmap, int NT,
+                                                        double *__restrict__ row)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= NT) return;
+    double acc = 0.0;
+#pragma unroll
+    for (int z = 0; z < TV_CS_SPLIT; ++z) acc += part[(long)z * NT + n];
+    row[cmap[n]] += acc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------
@@ -391,7 +418,7 @@ static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int
 }
 
 struct TvWs {
-    size_t off_mb, off_linv, off_e, off_tb, off_aux, off_eh32, off_map, off_auxs, total;
+    size_t off_mb, off_linv, off_e, off_tb, off_aux, off_eh32, off_map, off_cs, off_auxs, total;
     int ksplit;
 };
 
@@ -423,6 +450,8 @@ static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0)
     off += skm_align_up((size_t)S * R * sizeof(float), 256);
     w.off_map = off;
     off += skm_align_up((size_t)tv_tri_cols(R) * sizeof(int), 256);
+    w.off_cs = off;
+    off += skm_align_up((size_t)TV_CS_SPLIT * tv_tri_cols(R) * sizeof(double), 256);
     w.ksplit = (S > 0 && C > 0) ? tv_ksplit(cu, S, R, C) : 1;
     w.off_auxs = off;
     if (w.ksplit > 1) off += skm_align_up((size_t)w.ksplit * S * R * sizeof(double), 256);
@@ -556,14 +585,22 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         }
         SKM_HIP(hipGetLastError());
         if (train) {
-            // A[c] += sum_s N_sc e_hh(s); row C (the ones column of naug) accumulates _R
-            GemmArgs a = skm_gemm_args(naug + b0 * ldn, E, A_aug, C + 1, NT, nb, ldn, RR, RR);
+            // A[c] += sum_s N_sc e_hh(s).  Row C of A_aug (= _R, the plain sum of e_hh over the sessions) is NOT taken
+            // through the ones column of naug: C + 1 = 2049 rows would open a 17th row of 128-wide tiles for one
+            // row; a column-sum kernel reads E once instead (float64 sums, fixed order).
+            GemmArgs a = skm_gemm_args(naug + b0 * ldn, E, A_aug, C, NT, nb, ldn, RR, RR);
             a.transA = 1;
             a.beta = 1.0;
             a.colmap = cmap;
             a.colmap_vec = (R % 4 == 0);
             a.swz = 1;      // the component tiles of one e_hh column tile share it
             if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, a, 1, st, "k_gemm_aacc"))) return rc;
+            SkmProfScope ps(ctx, "k_ehh_colsum", st);
+            double *part = reinterpret_cast<double *>(ws + w.off_cs);      // TV_CS_SPLIT x NT doubles
+            hipLaunchKernelGGL(k_ehh_colsum, dim3((NT + 255) / 256, TV_CS_SPLIT), dim3(256), 0, st, E, RR, nb, cmap, NT, part);
+            hipLaunchKernelGGL(k_ehh_colsum_add, dim3((NT + 255) / 256), dim3(256), 0, st, part, cmap, NT,
+                               A_aug + (long)C * RR);
+            SKM_HIP(hipGetLastError());
         }
     }
     if (train) {

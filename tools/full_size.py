@@ -62,11 +62,11 @@ def main():
     T_dev = torch.as_tensor(0.1 * np.random.RandomState(7).randn(C * D, R), device=dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    T_dev = fa._tv_iteration(ft, naug, T_dev, C, D, R, S, True, 1024)
+    T_dev = fa._tv_iteration(ft, naug, T_dev, C, D, R, S, True, 4096)
     torch.cuda.synchronize()
     dt1 = time.perf_counter() - t0
     t0 = time.perf_counter()
-    T_dev = fa._tv_iteration(ft, naug, T_dev, C, D, R, S, True, 1024)
+    T_dev = fa._tv_iteration(ft, naug, T_dev, C, D, R, S, True, 4096)
     torch.cuda.synchronize()
     dt2 = time.perf_counter() - t0
     out["tv_train"] = {"seconds_iteration_1": dt1, "seconds_iteration_2": dt2, "sessions_per_s": S / dt2,
@@ -76,7 +76,7 @@ def main():
     T32, G = eng.tv_prepare(T_dev, C, D)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    e_h, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=1024, uncertainty=False)
+    e_h, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=4096, uncertainty=False)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out["extract_ivectors"] = {"seconds": dt, "ivectors_per_s": S / dt, "algorithmic_tflops": 4.5e8 * S / dt / 1e12,
