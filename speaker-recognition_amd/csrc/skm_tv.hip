@@ -604,12 +604,17 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         }
     }
     if (train) {
-        // C += e_h' f~ (factor_analyser.py:125)
-        GemmArgs c = skm_gemm_args(eh32, ftilde, Cacc, R, (int)CD, (int)S, R, CD, CD);
-        c.transA = 1;
-        c.beta = 1.0;
-        c.swz = 1;          // the R/128 row tiles share the f~ column tile
-        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, c, 1, st, "k_gemm_cacc"))) return rc;
+        // C += e_h' f~ (factor_analyser.py:125), one product per batch like the A accumulation: float32 MFMA sums over
+        // the <= `batch` sessions of a batch, float64 across batches (the plain k-loop with BK = 32 is 10 % faster here
+        // than one float64-folding product over all sessions)
+        for (long b0 = 0; b0 < S; b0 += batch) {
+            const int nb = (int)((S - b0) < batch ? (S - b0) : batch);
+            GemmArgs c = skm_gemm_args(eh32 + b0 * R, ftilde + b0 * CD, Cacc, R, (int)CD, nb, R, CD, CD);
+            c.transA = 1;
+            c.beta = 1.0;
+            c.swz = 1;      // the R/128 row tiles share the f~ column tile
+            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, c, 1, st, "k_gemm_cacc"))) return rc;
+        }
     }
     return SKM_OK;
 }
