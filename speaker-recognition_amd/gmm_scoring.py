@@ -42,14 +42,22 @@ def gmm_scoring_singleThread(ubm, enroll, ndx, feature_server, score_mat, seg_id
     if not seg_idx:
         return
     eng = ubm.engine
-    blocks, lens = _segment_frames(feature_server, ndx.segset[seg_idx])
-    for b in blocks:
-        if b.shape[1] != ubm.dim():
-            raise Exception('dimension of ubm and features differ: {:d} / {:d}'.format(ubm.dim(), b.shape[1]))
-    seg_off = np.concatenate([[0], np.cumsum(lens)])
-    if seg_off[-1] == 0:
-        return
-    X = eng.upload_frames(np.concatenate(blocks, axis=0))
+    if getattr(feature_server, "has_post_processing", lambda: False)() and hasattr(feature_server, "load_batch"):
+        # raw frames are post-processed on the GPU in one launch and stay there (what load() returns per segment)
+        X, seg_off, _ = feature_server.load_batch(list(ndx.segset[seg_idx]))
+        if X.shape[0] and X.shape[1] != ubm.dim():
+            raise Exception('dimension of ubm and features differ: {:d} / {:d}'.format(ubm.dim(), X.shape[1]))
+        if seg_off[-1] == 0:
+            return
+    else:
+        blocks, lens = _segment_frames(feature_server, ndx.segset[seg_idx])
+        for b in blocks:
+            if b.shape[1] != ubm.dim():
+                raise Exception('dimension of ubm and features differ: {:d} / {:d}'.format(ubm.dim(), b.shape[1]))
+        seg_off = np.concatenate([[0], np.cumsum(lens)])
+        if seg_off[-1] == 0:
+            return
+        X = eng.upload_frames(np.concatenate(blocks, axis=0))
     seg_off_dev = eng.torch.as_tensor(seg_off).to(eng.device)
     ubm_mean = eng.segment_mean(eng.loglik(X, ubm._pack()), seg_off_dev)
 
