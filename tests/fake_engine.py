@@ -53,6 +53,25 @@ class OracleEngine(object):
             return out
         return flat
 
+    def feat_postproc(self, X, seg_off, label=None, cols=None, rasta=False, ndelta=0, delta_filter=None, norm=0,
+                      global_mean=None, global_std=None, keep_all=True, out_dtype=None):
+        """Oracle post-processing (sidekit/features_server.py:202-246) session by session."""
+        x = X.numpy().astype(np.float64)
+        off = np.asarray(seg_off)
+        lab = np.ones(x.shape[0], dtype=bool) if label is None else np.asarray(label).astype(bool)
+        feats, labs, rows = [], [], [0]
+        for i in range(len(off) - 1):
+            f, l = orc.post_processing(x[off[i]:off[i + 1]], lab[off[i]:off[i + 1]], mask=cols, rasta=rasta,
+                                       delta=ndelta >= 1, double_delta=ndelta == 2,
+                                       delta_filter=orc.DELTA_FILTER if delta_filter is None else delta_filter,
+                                       feat_norm=[None, "cms", "cmvn"][norm], keep_all_features=keep_all,
+                                       global_mean=global_mean, global_std=global_std)
+            feats.append(f)
+            labs.append(l)
+            rows.append(rows[-1] + f.shape[0])
+        out = torch.from_numpy(np.vstack(feats)).to(out_dtype or torch.float32)
+        return out, torch.from_numpy(np.concatenate(labs).astype(np.uint8)), torch.from_numpy(np.array(rows))
+
     def moments(self, X):
         x = X.numpy().astype(np.float64)
         return torch.from_numpy(np.concatenate([x.sum(0), (x ** 2).sum(0)]))

@@ -96,9 +96,36 @@ def _worker(rank, world, port, tmp, q):
         out["iv"] = np.abs(ivs.stat1 - gt["iv"]).max() / np.abs(gt["iv"]).max()
         # ---- MAP adaptation + GMM-UBM scoring: test segments sharded, score matrix summed back
         out["sc"], out["map"] = _scoring_case(sk, eng)
+        # ---- raw cepstra through the post-processing server (batch path), sessions sharded over ranks
+        out["pp0"], out["pp1"] = _postproc_case(sk, eng, orc)
         q.put((rank, out))
     finally:
         td.destroy_process_group()
+
+
+def _postproc_case(sk, eng, orc):
+    """accumulate_stat fed by a FeaturesServer that post-processes raw frames (delta, double delta, cmvn, VAD
+    selection through load_batch) against the oracle's per-session post_processing + accumulate_stat."""
+    rs = np.random.RandomState(17)
+    D0, C = 5, 8
+    gmm = orc.random_gmm(C, 3 * D0, seed=2)
+    ubm = sk.Mixture(engine=eng)
+    ubm.w, ubm.mu, ubm.invcov = gmm.w.copy(), gmm.mu.copy(), gmm.invcov.copy()
+    ubm.cov_var_ctl = 1.0 / ubm.invcov
+    ubm._compute_all()
+    fs = sk.FeaturesServer(feat_norm="cmvn", delta=True, double_delta=True, keep_all_features=True, engine=eng)
+    names, sessions = [], []
+    for i in range(7):
+        L = int(rs.randint(20, 90))
+        x, lab = rs.randn(L, D0) * 2.0 + 1.0, rs.rand(L) > 0.3
+        fs.add("p%d" % i, x, lab)
+        names.append("p%d" % i)
+        f, l = orc.post_processing(x, lab, delta=True, double_delta=True, feat_norm="cmvn")
+        sessions.append(f[l])
+    ss = sk.StatServer(sk.IdMap().set(["m"] * len(names), names), ubm=ubm, engine=eng)
+    ss.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(len(names)))
+    s0, s1 = orc.accumulate_stat(gmm, sessions)
+    return np.abs(ss.stat0 - s0).max() / np.abs(s0).max(), np.abs(ss.stat1 - s1).max() / np.abs(s1).max()
 
 
 def _scoring_case(sk, eng):
@@ -161,6 +188,7 @@ def test_world2_gloo_matches_single_process(tmp_path):
         assert r["bw0"] < 1e-5 and r["bw1"] < 1e-5, r
         assert r["tv_F"] < 1e-5 and r["iv"] < 1e-5, r
         assert r["sc"] < 1e-4 and r["map"] < 1e-6, r
+        assert r["pp0"] < 1e-6 and r["pp1"] < 1e-6, r      # frames pass through float32 on their way to the statistics
     # both ranks hold the same model
     assert abs(res[0]["em_mu"] - res[1]["em_mu"]) < 1e-12
 
