@@ -1763,7 +1763,15 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
         for (int i = 0; i < KH; ++i) part[i] = __hip_atomic_load(row + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // gamma and statistics of tile `tile` (its e values are in lg, its partial rows in part[])
-    auto finish_tile = [&](f32x16 (&lg)[NCT], long tile) __attribute__((always_inline)) {
+    // Flag of a published row (the sc1 stores of the row are complete at the coherence point once acknowledged, so
+    // draining them is all the release this hand-off needs; an agent-scope release fence would write back the whole
+    // L2 every tile).  flag_val = 0: nothing to publish.
+    auto publish_flag = [&](int flag_slot, unsigned flag_val) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            __hip_atomic_store(flags + flag_slot * NC + me, flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto finish_tile = [&](f32x16 (&lg)[NCT], long tile, int flag_slot, unsigned flag_val) __attribute__((always_inline)) {
         const long t0 = tile << 5;
         const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
         float mx = -3.0e38f, sum = 0.f, m_me = 0.f;
@@ -1804,6 +1812,11 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
                 lg[ct][4 * q4 + 3] *= f4[3];
             }
         }
+        // The flag of the row published in THIS iteration goes out here: its stores are a barrier and the gamma
+        // arithmetic old, so the drain no longer stalls on their acknowledgement (~1 k cycles per tile when it sat
+        // right behind them), no vector load of this iteration is pending yet, and no control flow follows the
+        // statistics MFMAs.  The consumers look at the flag a logits GEMM later.
+        if (flag_val) publish_flag(flag_slot, flag_val);
         // frames of tile+3 are requested here (the statistics GEMM has no other vector-memory wait)
         if (tile + 3 < tb) {
             const long t3 = (tile + 3) << 5;
@@ -1901,18 +1914,14 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
                 const long t2 = (tile + 2) << 5;
                 stg.load(a.X, t2, (int)((a.T - t2) < 32 ? (a.T - t2) : 32), g.D);
             }
-            // flag of this tile's row: the sc1 stores issued above are complete at the coherence point once
-            // acknowledged, so draining them (by now they are old) is all the release this hand-off needs; an
-            // agent-scope release fence would write back the whole L2 (buffer_wbl2) every tile
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-                __hip_atomic_store(flags + slot * NC + me, (unsigned)(tile - ta) + 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            // the first tile has no finish_tile to carry its flag, the last one's consumers read it right after the loop
+            const bool early_flag = tile == ta || tile + 1 == tb;
+            if (early_flag) publish_flag(slot, (unsigned)(tile - ta) + 1u);
             SKM_STAMP(3);
             if (tile > ta) collect(tile - 1);   // the rows of tile-1 travel while the workgroup meets at the barrier
             __syncthreads();
             SKM_STAMP(4);
-            if (tile > ta) finish_tile(lg, tile - 1);
+            if (tile > ta) finish_tile(lg, tile - 1, slot, early_flag ? 0u : (unsigned)(tile - ta) + 1u);
             SKM_STAMP(6);
         }
         // the accumulators are touched by nothing but the asm MFMAs inside the tile loop: they stay in AGPRs
@@ -1930,7 +1939,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
                 }
             poll_issue(tb - 1);
             collect(tb - 1);
-            finish_tile(lg, tb - 1);
+            finish_tile(lg, tb - 1, 0, 0u);
         }
         flush_slab_agpr<NCT, NF>(acc, slab_lane);
     }
@@ -2030,7 +2039,14 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
     };
     // gamma and statistics of tile ni (its e values are in lg, its partial rows in part[]); t_pf >= 0 names
     // the frames to request for a later tile (the statistics GEMM has no other vector-memory wait)
-    auto finish_tile = [&](f32x16 (&lg)[NCT], unsigned ni, int nvalid, long t_pf, int nv_pf) __attribute__((always_inline)) {
+    // flag of a published row, as in k_estep_team (flag_val = 0: nothing to publish)
+    auto publish_flag = [&](int flag_slot, unsigned flag_val) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            __hip_atomic_store(flags + flag_slot * NC + me, flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto finish_tile = [&](f32x16 (&lg)[NCT], unsigned ni, int nvalid, long t_pf, int nv_pf, int flag_slot,
+                           unsigned flag_val) __attribute__((always_inline)) {
         float mx = -3.0e38f, sum = 0.f, m_me = 0.f;
         {
 #pragma unroll
@@ -2069,6 +2085,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
                 lg[ct][4 * q4 + 3] *= f4[3];
             }
         }
+        if (flag_val) publish_flag(flag_slot, flag_val);   // see k_estep_team: the drain is free here
         if (t_pf >= 0) stg.load(a.X, t_pf, nv_pf, g.D);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
@@ -2176,17 +2193,16 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
             if (i + 1 < ntile) stg.store(xs + nxt * tile_floats);
             // from here on finish_tile(i-1) requests tile i+2; the first iteration has no finish_tile
             if (i == 0 && ntile > 2) stg.load(a.X, b + 64, nv(2), g.D);
-            // flag of this tile's row: the sc1 stores issued above are complete at the coherence point once
-            // acknowledged, so draining them (by now they are old) is all the release this hand-off needs; an
-            // agent-scope release fence would write back the whole L2 (buffer_wbl2) every tile
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-                __hip_atomic_store(flags + slot * NC + me, ni + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // flag of this tile's row: carried by finish_tile(i-1) below unless this is the first or last tile
+            const bool early_flag = i == 0 || i + 1 == ntile;
+            if (early_flag) publish_flag(slot, ni + 1u);
             SKM_STAMP(3);
             if (i > 0) collect(ni - 1);   // the rows of tile i-1 travel while the workgroup meets at the barrier
             __syncthreads();
             SKM_STAMP(4);
-            if (i > 0) finish_tile(lg, ni - 1, nv(i - 1), (i + 2 < ntile) ? b + 32L * (i + 2) : -1L, (i + 2 < ntile) ? nv(i + 2) : 0);
+            if (i > 0)
+                finish_tile(lg, ni - 1, nv(i - 1), (i + 2 < ntile) ? b + 32L * (i + 2) : -1L, (i + 2 < ntile) ? nv(i + 2) : 0,
+                            slot, early_flag ? 0u : ni + 1u);
             SKM_STAMP(6);
         }
         {   // drain: the last tile of the segment
@@ -2204,7 +2220,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
             const unsigned nl = n + (unsigned)ntile - 1u;
             poll_issue(nl);
             collect(nl);
-            finish_tile(lg, nl, nv(ntile - 1), -1L, 0);
+            finish_tile(lg, nl, nv(ntile - 1), -1L, 0, 0, 0u);
         }
         n += (unsigned)ntile;
     };
