@@ -182,6 +182,36 @@ def test_bw_stats_team_kernel_ragged_and_empty_sessions(eng, C, D):
     assert rel(s0, eng.to_host(t0)) < 5e-5 and rel(s1, eng.to_host(t1)) < 5e-5   # two float32 paths, each within 1e-4 of the oracle
 
 
+@pytest.mark.parametrize("C,D", [(512, 60), (2048, 20)])
+def test_bw_stats_few_long_sessions_are_split(eng, C, D):
+    """Few long sessions on the team kernel: the host cuts them into 32-frame-aligned pieces (engine._bw_split_plan) and
+    adds the pieces' rows with a 0/1 float64 product.  Same statistics as the unsplit launch (the float32 MFMA accumulators
+    are folded into float64 at other tile boundaries: ~2e-6) and as the oracle; an empty session between two long ones
+    stays zero."""
+    gmm = orc.random_gmm(C, D, seed=31)
+    lens = [5000, 0, 3001, 2049]
+    frames = orc.synth_frames(sum(lens), dim=D, seed=32)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    plan = eng._bw_split_plan(off.astype(np.int64), C)
+    assert plan is not None and len(plan[1]) > len(lens)
+    pieces, owner = plan
+    assert pieces[0] == 0 and pieces[-1] == off[-1] and np.all(np.diff(pieces) >= 0)
+    assert set(off.tolist()) <= set(pieces.tolist())
+    for k, s in enumerate(owner):                                  # every piece lies inside its session, 32-aligned start
+        assert off[s] <= pieces[k] and pieces[k + 1] <= off[s + 1] and (pieces[k] - off[s]) % 32 == 0
+    X = eng.upload_frames(frames)
+    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    s0, s1 = eng.bw_stats(X, off, packed)
+    u0, u1 = eng.bw_stats(X, off, packed, split_long=False)
+    s0, s1, u0, u1 = eng.to_host(s0), eng.to_host(s1), eng.to_host(u0), eng.to_host(u1)
+    assert s0.shape == (len(lens), C) and s1.shape == (len(lens), C * D)
+    assert rel(s0, u0) < 2e-5 and rel(s1, u1) < 2e-5
+    assert np.all(s0[1] == 0) and np.all(s1[1] == 0)
+    r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
+    assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
+    assert np.allclose(s0.sum(1), lens, rtol=1e-4)
+
+
 def test_statserver_accumulate_stat_dropin(sk):
     g = golden("accumulate_stat.npz")
     sess, off = _sessions(g)

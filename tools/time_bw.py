@@ -9,6 +9,8 @@ X = synth_frames_device(torch, S * L, D, 1234, eng.device)
 ubm = random_ubm(sk, C, D)
 packed = eng.pack(ubm.w, ubm.mu, ubm.invcov)
 seg = torch.arange(0, S + 1, dtype=torch.int64, device=eng.device) * L
+if os.environ.get("SPLIT"):
+    seg = np.arange(0, S + 1, dtype=np.int64) * L           # host offsets: long sessions are cut over the teams
 s0 = torch.empty((S, C), dtype=torch.float64, device=eng.device)
 s1 = torch.empty((S, C * D), dtype=torch.float64, device=eng.device)
 eng.bw_stats(X, seg, packed, s0, s1)
