@@ -191,6 +191,30 @@ int skm_tv_mstep(void *ctx, double *A_aug_dev, const double *Cacc_dev, int C, in
  * (sidekit/iv_scoring.py:96-98); the score matrix itself (iv_scoring.py:99) is skm_gemm with transB. */
 int skm_row_normalize(void *ctx, double *X_dev, long S, int R, void *stream);
 
+/* Class sums / means of rows: out_dev[k*R + j] = alpha * (mean ? 1/n_k : 1) * sum_{i in [cls_off[k], cls_off[k+1])}
+ * X_dev[src[i]*ldx + j]; src_dev (S int64: the sessions sorted by class) may be NULL = identity; an empty class with
+ * mean = 1 gives NaN.  Replaces the per-speaker `numpy.mean(self.get_model_stat1(id), axis=0)` / `.sum(axis=0)` loops
+ * of sidekit/statserver.py:818-824, 843-846, 868-872, 913-917, 1222-1224, 1242-1244 and `get_mean_stat1` (:669-675). */
+int skm_class_sums(void *ctx, const double *X_dev, long ldx, const int64_t *src_dev, const int64_t *cls_off_dev, int K,
+                   int R, int mean, double alpha, double *out_dev, void *stream);
+
+/* out_dev[i*R + j] = (X_dev[src[i]*ldx + j] - Mu_dev[cls[i]*R + j]) * scale[i]; src NULL = i, cls NULL = row 0 of Mu,
+ * Mu NULL = nothing subtracted, scale NULL = 1.  The centring `get_model_stat1(id) - mean` of the same loops (with
+ * scale = 1/sqrt(n_k) the scatter GEMM of the centred rows is the `/ spk_ctr_vec.shape[0]`-weighted sum of
+ * statserver.py:871,917) and `stat1 - mean` of :807 / center_stat1 on i-vectors (:690-697). */
+int skm_rows_center(void *ctx, const double *X_dev, long ldx, const int64_t *src_dev, const int64_t *cls_dev,
+                    const double *Mu_dev, const double *scale_dev, long S, int R, double *out_dev, void *stream);
+
+/* out_dev[i] = sum_j A_dev[i*R + j] * B_dev[i*R + j]: with B = X.M the quadratic forms x'Mx of
+ * sidekit/iv_scoring.py:142,192-193,197. */
+int skm_row_dot(void *ctx, const double *A_dev, const double *B_dev, long S, int R, double *out_dev, void *stream);
+
+/* Sc_dev[i*N + j] = alpha * Sc_dev[i*N + j] + ca * a_dev[i] + cb * b_dev[j]: the score matrix of
+ * mahalanobis_scoring (iv_scoring.py:139-142) and two_covariance_scoring (:195-198) from the cross-term GEMM and the
+ * per-row quadratic forms. */
+int skm_pair_combine(void *ctx, double *Sc_dev, long M, long N, double alpha, const double *a_dev, double ca,
+                     const double *b_dev, double cb, void *stream);
+
 /* ------------------------------------------------------------------ feature post-processing (next row) ---- */
 
 /* FeaturesServer.post_processing (sidekit/features_server.py:202-246) for a batch of S sessions whose raw

@@ -536,3 +536,108 @@ def post_processing(feat, label, mask=None, rasta=False, delta=False, double_del
         feat = feat[label]
         label = label[label]
     return feat, label
+
+
+# ------------------------------------------------------------------ i-vector back-end (next row)
+def _classes(modelset):
+    """Unique model names in numpy.unique order and the row indices of each."""
+    modelset = np.asarray(modelset)
+    uniq = np.unique(modelset)
+    return uniq, [np.flatnonzero(modelset == u) for u in uniq]
+
+
+def total_covariance(x):
+    """sidekit/statserver.py:800-808."""
+    c = x - x.mean(axis=0)
+    return np.dot(c.T, c) / x.shape[0]
+
+
+def within_covariance(modelset, x):
+    """sidekit/statserver.py:810-826."""
+    W = np.zeros((x.shape[1], x.shape[1]))
+    for rows in _classes(modelset)[1]:
+        c = x[rows] - x[rows].mean(axis=0)
+        W += np.dot(c.T, c)
+    return W / x.shape[0]
+
+
+def between_covariance(modelset, x):
+    """sidekit/statserver.py:828-848."""
+    B = np.zeros((x.shape[1], x.shape[1]))
+    mu = x.mean(axis=0)
+    for rows in _classes(modelset)[1]:
+        d = x[rows].mean(axis=0) - mu
+        B += rows.size * np.outer(d, d)
+    return B / x.shape[0]
+
+
+def lda_matrix(modelset, x, rank):
+    """sidekit/statserver.py:850-889 (scipy's eigh of the non-symmetric discrimination matrix reads its lower
+    triangle only: kept)."""
+    uniq, cls = _classes(modelset)
+    mu = x.mean(axis=0)
+    Sw = np.zeros((x.shape[1], x.shape[1]))
+    means = np.zeros((len(cls), x.shape[1]))
+    for k, rows in enumerate(cls):
+        c = x[rows] - x[rows].mean(axis=0)
+        Sw += np.dot(c.T, c) / rows.size
+        means[k] = x[rows].mean(axis=0)
+    means = means - mu
+    Sb = np.dot(means.T, means)
+    ev, evec = scipy.linalg.eigh(np.dot(Sb, scipy.linalg.inv(Sw)).T)
+    return evec.real[:, ev.real.argsort()[-rank:][::-1]]
+
+
+def wccn_choleski(modelset, x):
+    """sidekit/statserver.py:901-925."""
+    uniq, cls = _classes(modelset)
+    W = np.zeros((x.shape[1], x.shape[1]))
+    for rows in cls:
+        c = x[rows] - x[rows].mean(axis=0)
+        W += np.dot(c.T, c) / rows.size
+    W = W / len(cls)
+    return scipy.linalg.cholesky(scipy.linalg.inv(W)).T
+
+
+def mean_per_model(modelset, x):
+    """sidekit/statserver.py:1228-1245 (first-order part)."""
+    uniq, cls = _classes(modelset)
+    return uniq, np.array([x[rows].mean(axis=0) for rows in cls])
+
+
+def whiten_full(x, mu, sigma, is_sqr_inv_sigma=False):
+    """sidekit/statserver.py:747-764 for i-vectors (stat0 = 1)."""
+    sq = sigma
+    if not is_sqr_inv_sigma:
+        ev, evec = scipy.linalg.eigh(sigma)
+        ind = ev.real.argsort()[::-1]
+        sq = np.dot(evec.real[:, ind], np.diag(1 / np.sqrt(ev.real[ind])))
+    return np.dot(x - mu, sq)
+
+
+def whiten_cholesky(x, mu, sigma):
+    """sidekit/statserver.py:778-792."""
+    return np.dot(x - mu, scipy.linalg.cholesky(scipy.linalg.inv(sigma)).T)
+
+
+def mahalanobis_scores(enroll_iv, test_iv, m):
+    """sidekit/iv_scoring.py:138-142."""
+    s = np.zeros((enroll_iv.shape[0], test_iv.shape[0]))
+    for i in range(enroll_iv.shape[0]):
+        diff = enroll_iv[i] - test_iv
+        s[i] = -0.5 * np.sum(np.dot(diff, m) * diff, axis=1)
+    return s
+
+
+def two_covariance_scores(enroll_iv, test_iv, W, B):
+    """sidekit/iv_scoring.py:184-198."""
+    iW, iB = scipy.linalg.inv(W), scipy.linalg.inv(B)
+    G = iW.dot(scipy.linalg.inv(iB + 2 * iW)).dot(iW)
+    H = iW.dot(scipy.linalg.inv(iB + iW)).dot(iW)
+    s2 = np.sum(np.dot(enroll_iv, H) * enroll_iv, axis=1)
+    s3 = np.sum(np.dot(test_iv, H) * test_iv, axis=1)
+    S = np.zeros((enroll_iv.shape[0], test_iv.shape[0]))
+    for i in range(enroll_iv.shape[0]):
+        A = enroll_iv[i] + test_iv
+        S[i] = np.sum(np.dot(A, G) * A, axis=1) - s3 - s2[i]
+    return S

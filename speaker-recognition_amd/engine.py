@@ -43,6 +43,13 @@ SIGNATURES = {
                               _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "skm_segment_mean": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "skm_row_normalize": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
+    "skm_class_sums": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                ctypes.c_double, _c_void_p, _c_void_p]),
+    "skm_rows_center": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long,
+                                 _c_int, _c_void_p, _c_void_p]),
+    "skm_row_dot": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p]),
+    "skm_pair_combine": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_long, ctypes.c_double, _c_void_p, ctypes.c_double,
+                                  _c_void_p, ctypes.c_double, _c_void_p]),
     "skm_gemm": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_long,
                           _c_long, _c_long, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int, _c_long,
                           _c_long, _c_long, _c_void_p]),
@@ -405,6 +412,75 @@ class HipEngine(object):
                                       1 if transA else 0, 1 if transB else 0, float(alpha), float(beta), 1, 0, 0, 0,
                                       self._stream()))
         return C
+
+    # ------------------------------------------------------------------ i-vector back-end reductions (float64)
+    def _f64_dev(self, x):
+        torch = self.torch
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=torch.float64).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(self.device)
+
+    def _i64_dev(self, x):
+        torch = self.torch
+        if x is None:
+            return None
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=torch.int64).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(x, dtype=np.int64)).to(self.device)
+
+    @staticmethod
+    def _ptr(t):
+        return _c_void_p(t.data_ptr()) if t is not None else None
+
+    def class_sums(self, X, cls_off, src=None, mean=False, alpha=1.0):
+        """K x R sums (or means) of the rows X[src[cls_off[k]:cls_off[k+1]]] of a float64 device matrix."""
+        assert X.dim() == 2 and X.dtype == self.torch.float64 and X.is_contiguous()
+        cls_off, src = self._i64_dev(cls_off), self._i64_dev(src)
+        K = cls_off.numel() - 1
+        out = self.torch.empty((K, X.shape[1]), dtype=self.torch.float64, device=self.device)
+        self._check(self.lib.skm_class_sums(self.ctx, self._ptr(X), X.shape[1], self._ptr(src), self._ptr(cls_off), K,
+                                            X.shape[1], 1 if mean else 0, float(alpha), self._ptr(out), self._stream()))
+        return out
+
+    def col_mean(self, X):
+        """1 x R column mean of a float64 device matrix, two levels of fixed-order sums (chunks of 128 rows)."""
+        S = X.shape[0]
+        off = np.append(np.arange(0, S, 128, dtype=np.int64), S)
+        part = self.class_sums(X, off)
+        return self.class_sums(part, np.array([0, part.shape[0]], dtype=np.int64), alpha=1.0 / max(S, 1))
+
+    def rows_center(self, X, Mu=None, cls=None, src=None, scale=None):
+        """(X[src[i]] - Mu[cls[i]]) * scale[i] as a new S x R float64 device matrix."""
+        torch = self.torch
+        assert X.dim() == 2 and X.dtype == torch.float64 and X.is_contiguous()
+        src, cls = self._i64_dev(src), self._i64_dev(cls)
+        S = X.shape[0] if src is None else src.numel()
+        R = X.shape[1]
+        if Mu is not None:
+            Mu = self._f64_dev(Mu).reshape(-1, R)
+        if scale is not None:
+            scale = self._f64_dev(scale)
+            assert scale.numel() == S
+        assert cls is None or (Mu is not None and cls.numel() == S)
+        out = torch.empty((S, R), dtype=torch.float64, device=self.device)
+        self._check(self.lib.skm_rows_center(self.ctx, self._ptr(X), R, self._ptr(src), self._ptr(cls), self._ptr(Mu),
+                                             self._ptr(scale), S, R, self._ptr(out), self._stream()))
+        return out
+
+    def row_dot(self, A, B):
+        assert A.shape == B.shape and A.dtype == B.dtype == self.torch.float64 and A.is_contiguous() and B.is_contiguous()
+        out = self.torch.empty((A.shape[0],), dtype=self.torch.float64, device=self.device)
+        self._check(self.lib.skm_row_dot(self.ctx, self._ptr(A), self._ptr(B), A.shape[0], A.shape[1], self._ptr(out),
+                                         self._stream()))
+        return out
+
+    def pair_combine_(self, Sc, a, b, alpha=1.0, ca=1.0, cb=1.0):
+        """In place: Sc[i, j] = alpha Sc[i, j] + ca a[i] + cb b[j]."""
+        assert Sc.dim() == 2 and Sc.dtype == self.torch.float64 and Sc.is_contiguous()
+        assert a.numel() == Sc.shape[0] and b.numel() == Sc.shape[1]
+        self._check(self.lib.skm_pair_combine(self.ctx, self._ptr(Sc), Sc.shape[0], Sc.shape[1], float(alpha),
+                                              self._ptr(a), float(ca), self._ptr(b), float(cb), self._stream()))
+        return Sc
 
     def row_normalize_(self, X):
         """In-place length normalisation of the rows of a float64 device matrix (norm clipped at 1e-8)."""

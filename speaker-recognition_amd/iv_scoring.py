@@ -1,8 +1,9 @@
-"""Cosine scoring of i-vectors with the surface of sidekit/iv_scoring.py:61-106 (the step
+"""Cosine, Mahalanobis and two-covariance scoring of i-vectors with the surface of sidekit/iv_scoring.py:61-205 (the step
 after extract_ivectors in i-vector.py:189).  Optional WCCN rotation, length normalisation of both sets and the
 score matrix enroll . test' run on the GPU: skm_gemm (float64 MFMA) and skm_row_normalize.  The trial mask does
 not restrict the product (the reference scores every pair as well, iv_scoring.py:99)."""
 import copy
+import logging
 
 import numpy as np
 
@@ -46,3 +47,69 @@ def cosine_scoring(enroll, test, ndx, wccn=None, check_missing=True):
     score.segset = clean_ndx.segset
     score.scoremask = clean_ndx.trialmask
     return score
+
+
+def _unique_models(enroll):
+    """iv_scoring.py:127-130 / :173-176."""
+    if not np.unique(enroll.modelset).shape == enroll.modelset.shape:
+        logging.warning("Enrollment models are not unique, average i-vectors")
+        enroll = enroll.mean_stat_per_model()
+    return enroll
+
+
+def _pair_scores(eng, E, T, G, Q, alpha, ca, cb):
+    """alpha (e'G t + t'G e) + ca e'Q e + cb t'Q t for every (enrolment, test) pair: two R x R products per set, two
+    cross-term GEMMs accumulated into the score matrix, two row-wise quadratic forms."""
+    G, Q = eng._f64_dev(G), eng._f64_dev(Q)
+    EG, TG = eng.gemm(E, G), eng.gemm(T, G)
+    qe = eng.row_dot(EG if Q is G else eng.gemm(E, Q), E)
+    qt = eng.row_dot(TG if Q is G else eng.gemm(T, Q), T)
+    S = eng.gemm(EG, T, transB=True)
+    S = eng.gemm(E, TG, C=S, transB=True, beta=1.0)
+    return eng.pair_combine_(S, qe, qt, alpha=alpha, ca=ca, cb=cb)
+
+
+def _finish(s, clean_ndx):
+    score = Scores()
+    score.scoremat = s
+    score.modelset = clean_ndx.modelset
+    score.segset = clean_ndx.segset
+    score.scoremask = clean_ndx.trialmask
+    return score
+
+
+def mahalanobis_scoring(enroll, test, ndx, m, check_missing=True):
+    """-0.5 (e - t)' m (e - t) for all pairs (iv_scoring.py:109-149); like the reference, aligns `enroll` / `test` in
+    place.  (e-t)'m(e-t) = e'me + t'mt - e'mt - t'me: the cross terms are GEMMs."""
+    assert isinstance(enroll, StatServer), 'First parameter should be a StatServer'
+    assert isinstance(test, StatServer), 'Second parameter should be a StatServer'
+    assert isinstance(ndx, Ndx), 'Third parameter should be an Ndx'
+    assert enroll.stat1.shape[1] == test.stat1.shape[1], 'I-vectors dimension mismatch'
+    assert enroll.stat1.shape[1] == m.shape[0], 'I-vectors and Mahalanobis matrix dimension mismatch'
+    enroll = _unique_models(enroll)
+    clean_ndx = _check_missing_model(enroll, test, ndx) if check_missing else ndx
+    eng = enroll.engine
+    m = eng._f64_dev(m)
+    s = _pair_scores(eng, eng._f64_dev(enroll.stat1), eng._f64_dev(test.stat1), m, m, 0.5, -0.5, -0.5)
+    return _finish(eng.to_host(s), clean_ndx)
+
+
+def two_covariance_scoring(enroll, test, ndx, W, B, check_missing=True):
+    """(e+t)'G(e+t) - t'Ht - e'He for all pairs (iv_scoring.py:152-205); G and H from three R x R host inverses as in
+    the reference, the pair terms on the device: e'Gt + t'Ge + e'(G-H)e + t'(G-H)t."""
+    import scipy.linalg
+    assert isinstance(enroll, StatServer), 'First parameter should be a directory'
+    assert isinstance(test, StatServer), 'Second parameter should be a StatServer'
+    assert isinstance(ndx, Ndx), 'Third parameter should be an Ndx'
+    assert enroll.stat1.shape[1] == test.stat1.shape[1], 'I-vectors dimension mismatch'
+    assert enroll.stat1.shape[1] == W.shape[0], 'I-vectors and co-variance matrix dimension mismatch'
+    assert enroll.stat1.shape[1] == B.shape[0], 'I-vectors and co-variance matrix dimension mismatch'
+    enroll = _unique_models(enroll)
+    clean_ndx = _check_missing_model(enroll, test, ndx) if check_missing else ndx
+    iW = scipy.linalg.inv(W)
+    iB = scipy.linalg.inv(B)
+    G = iW.dot(scipy.linalg.inv(iB + 2 * iW)).dot(iW)
+    H = iW.dot(scipy.linalg.inv(iB + iW)).dot(iW)
+    eng = enroll.engine
+    s = _pair_scores(eng, eng._f64_dev(enroll.stat1), eng._f64_dev(test.stat1), G, G - H, 1.0, 1.0, 1.0)
+    return _finish(eng.to_host(s), clean_ndx)

@@ -287,12 +287,115 @@ class StatServer(object):
         self.stat1 = self.stat1 - (self.stat0[:, index_map] * mu.astype(STAT_TYPE))
 
     def whiten_stat1(self, mu, sigma, isSqrInvSigma=False):
-        """Diagonal whitening only (statserver.py:743-745)."""
-        if sigma.ndim != 1:
-            raise Exception('only the diagonal-covariance whitening is on this path')
-        self.center_stat1(mu)
-        self.stat1 = self.stat1 / np.sqrt(sigma.astype(STAT_TYPE))
+        """Diagonal (statserver.py:743-745) and single full-covariance (:747-764) whitening; the R x R eigen-decomposition
+        is host LAPACK like the reference's, the rotation of the S rows a device GEMM."""
+        if sigma.ndim == 1:
+            self.center_stat1(mu)
+            self.stat1 = self.stat1 / np.sqrt(sigma.astype(STAT_TYPE))
+        elif sigma.ndim == 2:
+            sqr_inv_sigma = sigma
+            if not isSqrInvSigma:
+                import scipy.linalg
+                eigen_values, eigen_vectors = scipy.linalg.eigh(sigma)
+                ind = eigen_values.real.argsort()[::-1]
+                sqr_inv_sigma = np.dot(eigen_vectors.real[:, ind], np.diag(1 / np.sqrt(eigen_values.real[ind])))
+            self.center_stat1(mu)
+            self.rotate_stat1(sqr_inv_sigma)
+        else:
+            raise Exception('full-covariance UBM whitening (sigma.ndim == 3) is not on this path')
 
+    def whiten_cholesky_stat1(self, mu, sigma):
+        """statserver.py:778-798."""
+        if sigma.ndim == 2:
+            import scipy.linalg
+            chol_invcov = scipy.linalg.cholesky(scipy.linalg.inv(sigma)).T
+            self.center_stat1(mu)
+            self.rotate_stat1(chol_invcov)
+        elif sigma.ndim == 1:
+            self.center_stat1(mu)
+            self.stat1 = self.stat1 / np.sqrt(sigma)
+        else:
+            raise Exception('Wrong dimension of Sigma, must be 1 or 2')
+
+    # ------------------------------------------------------------------ i-vector back-end (SURVEY 8f rank 3)
+    # Every scatter matrix below is ONE float64 MFMA GEMM Xc' Xc over centred (and 1/sqrt(n)-scaled) rows; class
+    # means and the centring are skm_class_sums / skm_rows_center over the sessions sorted by speaker.  The R x R
+    # inverse / Cholesky / eigen-decomposition that follow stay host LAPACK, like the reference's.
+    def _class_layout(self):
+        uniq, inv = np.unique(self.modelset, return_inverse=True)
+        order = np.argsort(inv, kind="stable").astype(np.int64)
+        counts = np.bincount(inv, minlength=uniq.shape[0]).astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        return uniq, inv[order].astype(np.int64), order, counts, off
+
+    def _class_centred(self, weighted):
+        """(device X, class means K x R, rows sorted by class minus their class mean [times 1/sqrt(n_k)], counts)."""
+        eng = self.engine
+        uniq, cls_sorted, order, counts, off = self._class_layout()
+        X = eng._f64_dev(self.stat1)
+        means = eng.class_sums(X, off, src=order, mean=True)
+        scale = (1.0 / np.sqrt(counts.astype(np.float64)))[cls_sorted] if weighted else None
+        return X, means, eng.rows_center(X, Mu=means, cls=cls_sorted, src=order, scale=scale), counts
+
+    def get_total_covariance_stat1(self):
+        """statserver.py:800-808."""
+        eng = self.engine
+        X = eng._f64_dev(self.stat1)
+        Xc = eng.rows_center(X, Mu=eng.col_mean(X))
+        return eng.to_host(eng.gemm(Xc, Xc, transA=True, alpha=1.0 / self.stat1.shape[0]))
+
+    def get_within_covariance_stat1(self):
+        """statserver.py:810-826."""
+        eng = self.engine
+        Xc = self._class_centred(False)[2]
+        return eng.to_host(eng.gemm(Xc, Xc, transA=True, alpha=1.0 / self.stat1.shape[0]))
+
+    def get_between_covariance_stat1(self):
+        """statserver.py:828-848: sum_k n_k (m_k - mu)(m_k - mu)' / S."""
+        eng = self.engine
+        uniq, cls_sorted, order, counts, off = self._class_layout()
+        X = eng._f64_dev(self.stat1)
+        means = eng.class_sums(X, off, src=order, mean=True)
+        Mc = eng.rows_center(means, Mu=eng.col_mean(X), scale=np.sqrt(counts.astype(np.float64)))
+        return eng.to_host(eng.gemm(Mc, Mc, transA=True, alpha=1.0 / self.stat1.shape[0]))
+
+    def get_lda_matrix_stat1(self, rank):
+        """statserver.py:850-889 (scipy's eigh on the non-symmetric discrimination matrix, as the reference)."""
+        import scipy.linalg
+        eng = self.engine
+        X, means, Xc, counts = self._class_centred(True)
+        Sw = eng.to_host(eng.gemm(Xc, Xc, transA=True))
+        Mc = eng.rows_center(means, Mu=eng.col_mean(X))
+        Sb = eng.to_host(eng.gemm(Mc, Mc, transA=True))
+        eigen_values, eigen_vectors = scipy.linalg.eigh(np.dot(Sb, scipy.linalg.inv(Sw)).transpose())
+        idx = eigen_values.real.argsort()[-rank:][::-1]
+        return eigen_vectors.real[:, idx]
+
+    def get_mahalanobis_matrix_stat1(self):
+        """statserver.py:891-899."""
+        import scipy.linalg
+        return scipy.linalg.inv(self.get_within_covariance_stat1())
+
+    def get_wccn_choleski_stat1(self):
+        """statserver.py:901-925."""
+        import scipy.linalg
+        eng = self.engine
+        X, means, Xc, counts = self._class_centred(True)
+        WCCN = eng.to_host(eng.gemm(Xc, Xc, transA=True, alpha=1.0 / counts.shape[0]))
+        return scipy.linalg.cholesky(scipy.linalg.inv(WCCN)).T
+
+    def mean_stat_per_model(self):
+        """statserver.py:1228-1245."""
+        eng = self.engine
+        uniq, cls_sorted, order, counts, off = self._class_layout()
+        out = StatServer(engine=self._engine)
+        out.modelset = uniq
+        out.segset = out.modelset
+        out.start = np.empty(out.segset.shape, '|O')
+        out.stop = np.empty(out.segset.shape, '|O')
+        out.stat0 = eng.to_host(eng.class_sums(eng._f64_dev(self.stat0), off, src=order, mean=True))
+        out.stat1 = eng.to_host(eng.class_sums(eng._f64_dev(self.stat1), off, src=order, mean=True))
+        return out
 
     def _take(self, indx):
         self.segset = self.segset[indx]
@@ -311,8 +414,9 @@ class StatServer(object):
         self._take(np.array([np.argwhere(self.modelset == v)[0][0] for v in model_list], dtype=np.int64))
 
     def rotate_stat1(self, R):
-        """stat1 <- stat1 . R (statserver.py:682-688)."""
-        self.stat1 = np.dot(self.stat1, R)
+        """stat1 <- stat1 . R (statserver.py:682-688), a float64 device GEMM."""
+        eng = self.engine
+        self.stat1 = eng.to_host(eng.gemm(eng._f64_dev(self.stat1), eng._f64_dev(R)))
 
     # ------------------------------------------------------------------ MAP adaptation (feeds gmm_scoring)
     # C*D element-wise float64 updates on already-reduced statistics: host, like the GMM M-step.

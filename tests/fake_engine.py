@@ -136,8 +136,49 @@ class OracleEngine(object):
             Fm[c * D:(c + 1) * D] = np.linalg.solve(A[c], Cc[:, c * D:(c + 1) * D]).T
         return torch.from_numpy(Fm)
 
-    def gemm(self, A, B, transB=False, **kw):
-        return torch.from_numpy(A.numpy().dot(B.numpy().T if transB else B.numpy()))
+    def gemm(self, A, B, C=None, transA=False, transB=False, alpha=1.0, beta=0.0, **kw):
+        a = A.numpy().T if transA else A.numpy()
+        r = alpha * a.dot(B.numpy().T if transB else B.numpy())
+        if C is not None and beta != 0.0:
+            r = r + beta * C.numpy()
+        return torch.from_numpy(np.ascontiguousarray(r))
+
+    # i-vector back-end reductions (numpy statements of the skm_class_sums / skm_rows_center / skm_row_dot /
+    # skm_pair_combine contracts in include/skm.h)
+    def _f64_dev(self, x):
+        return x.double().contiguous() if isinstance(x, torch.Tensor) else \
+            torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+
+    def class_sums(self, X, cls_off, src=None, mean=False, alpha=1.0):
+        x = X.numpy()
+        off = np.asarray(cls_off, dtype=np.int64)
+        src = np.arange(x.shape[0]) if src is None else np.asarray(src, dtype=np.int64)
+        out = np.zeros((off.size - 1, x.shape[1]))
+        for k in range(off.size - 1):
+            rows = x[src[off[k]:off[k + 1]]]
+            out[k] = alpha * (rows.mean(axis=0) if mean else rows.sum(axis=0))
+        return torch.from_numpy(out)
+
+    def col_mean(self, X):
+        return torch.from_numpy(X.numpy().mean(axis=0, keepdims=True))
+
+    def rows_center(self, X, Mu=None, cls=None, src=None, scale=None):
+        x = X.numpy()
+        x = x if src is None else x[np.asarray(src, dtype=np.int64)]
+        if Mu is not None:
+            mu = self._f64_dev(Mu).numpy().reshape(-1, x.shape[1])
+            x = x - (mu[0] if cls is None else mu[np.asarray(cls, dtype=np.int64)])
+        if scale is not None:
+            x = x * self._f64_dev(scale).numpy()[:, None]
+        return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+
+    def row_dot(self, A, B):
+        return torch.from_numpy((A.numpy() * B.numpy()).sum(axis=1))
+
+    def pair_combine_(self, Sc, a, b, alpha=1.0, ca=1.0, cb=1.0):
+        s = Sc.numpy()
+        s[...] = alpha * s + ca * a.numpy()[:, None] + cb * b.numpy()[None, :]
+        return Sc
 
     def row_normalize_(self, X):
         x = X.numpy()

@@ -1,0 +1,64 @@
+"""GPU parity of the i-vector back-end: skm_class_sums / skm_rows_center / skm_row_dot /
+skm_pair_combine + float64 MFMA GEMMs through the C ABI, against the real reference's outputs (golden) and the oracle
+at a larger, ragged size."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import sidekit_ref as orc  # noqa: E402
+from backend_case import run_backend_case, _server, _close  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sk():
+    import sidekit_amd
+    return sidekit_amd
+
+
+@pytest.fixture(scope="module")
+def eng(sk):
+    return sk.default_engine()
+
+
+def test_backend_vs_reference_golden(sk, eng):
+    run_backend_case(sk, eng)
+
+
+def test_backend_reductions_ragged_vs_oracle(sk, eng):
+    """R = 83 (not a multiple of 64), 700 sessions of 37 speakers with 1..60 sessions each in shuffled order."""
+    rs = np.random.RandomState(5)
+    R, K = 83, 37
+    counts = rs.randint(1, 61, size=K)
+    counts[:3] = [1, 2, 60]
+    models = np.repeat(["s%03d" % k for k in range(K)], counts)
+    x = (rs.randn(K, R) * 2.0)[np.repeat(np.arange(K), counts)] + rs.randn(counts.sum(), R) + 3.0
+    p = rs.permutation(models.size)
+    models, x = models[p], x[p]
+    ss = _server(sk, eng, models, ["g%d" % i for i in range(models.size)], x)
+    _close(ss.get_total_covariance_stat1(), orc.total_covariance(x), 1e-11)
+    _close(ss.get_within_covariance_stat1(), orc.within_covariance(models, x), 1e-11)
+    _close(ss.get_between_covariance_stat1(), orc.between_covariance(models, x), 1e-11)
+    _close(ss.get_wccn_choleski_stat1(), orc.wccn_choleski(models, x), 1e-9)
+    uniq, means = orc.mean_per_model(models, x)
+    mps = ss.mean_stat_per_model()
+    assert list(mps.modelset) == list(uniq)
+    _close(mps.stat1, means, 1e-13)
+    X = eng._f64_dev(x)
+    _close(eng.to_host(eng.col_mean(X))[0], x.mean(axis=0), 1e-13)
+    # pair scores at a shape with edge tiles on both sides
+    E, T = rs.randn(130, R), rs.randn(517, R)
+    M = orc.within_covariance(models, x)
+    e = _server(sk, eng, ["m%d" % i for i in range(130)], ["m%d" % i for i in range(130)], E)
+    t = _server(sk, eng, ["t%d" % i for i in range(517)], ["t%d" % i for i in range(517)], T)
+    ndx = sk.Ndx()
+    ndx.modelset, ndx.segset = e.modelset.copy(), t.segset.copy()
+    ndx.trialmask = np.ones((130, 517), dtype=bool)
+    _close(sk.mahalanobis_scoring(e, t, ndx, M).scoremat, orc.mahalanobis_scores(E, T, M), 1e-11)
+    B = orc.between_covariance(models, x)
+    _close(sk.two_covariance_scoring(e, t, ndx, M, B).scoremat, orc.two_covariance_scores(E, T, M, B), 1e-10)

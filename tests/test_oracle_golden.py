@@ -205,6 +205,46 @@ def test_cosine_scoring_oracle_and_host_logic_vs_reference_golden():
     close(sw, g["scoremat_wccn"], rtol=1e-12)
 
 
+def test_iv_backend_oracle_vs_reference_golden():
+    """SURVEY 8f rank 3 (remainder): covariance / LDA / WCCN / Mahalanobis matrices, whitening, mahalanobis_scoring and
+    two_covariance_scoring of the real reference (tools/gen_golden.py gen_backend) against the oracle's restatement."""
+    g = golden("iv_backend.npz")
+    ms, x = g["modelset"], g["stat1"]
+    close(orc.total_covariance(x), g["total_cov"], rtol=1e-12)
+    close(orc.within_covariance(ms, x), g["within_cov"], rtol=1e-12)
+    close(orc.between_covariance(ms, x), g["between_cov"], rtol=1e-12)
+    close(orc.lda_matrix(ms, x, int(g["lda_rank"])), g["lda"], rtol=1e-9)
+    close(scipy_inv(orc.within_covariance(ms, x)), g["mahalanobis_matrix"], rtol=1e-11)
+    close(orc.wccn_choleski(ms, x), g["wccn_chol"], rtol=1e-11)
+    uniq, means = orc.mean_per_model(ms, x)
+    assert list(uniq) == list(g["mean_per_model_modelset"])
+    close(means, g["mean_per_model_stat1"], rtol=1e-13)
+    close(orc.whiten_full(x, g["mu"], g["total_cov"]), g["whitened_full"], rtol=1e-10)
+    close(orc.whiten_cholesky(x, g["mu"], g["total_cov"]), g["whitened_chol"], rtol=1e-10)
+    close(orc.whiten_full(x, g["mu"], g["wccn_chol"], True), g["whitened_presqrt"], rtol=1e-12)
+    # the scorers average repeated enrolment models, then follow the cleaned Ndx
+    uniq, e_mean = orc.mean_per_model(g["enroll_modelset"], g["enroll_iv"])
+    e = e_mean[[list(uniq).index(m) for m in g["maha_modelset"]]]
+    t = g["test_iv"][[list(g["test_segset"]).index(sg) for sg in g["maha_segset"]]]
+    close(orc.mahalanobis_scores(e, t, g["mahalanobis_matrix"]), g["maha_scoremat"], rtol=1e-12)
+    close(orc.mahalanobis_scores(e, t, g["maha_nonsym_matrix"]), g["maha_nonsym_scoremat"], rtol=1e-12)
+    close(orc.two_covariance_scores(e, t, g["within_cov"], g["between_cov"]), g["twocov_scoremat"], rtol=1e-11)
+
+
+def test_iv_backend_host_logic_vs_reference_golden():
+    """The drop-in StatServer / iv_scoring back-end methods (class layout, alignment, averaging of repeated models, the
+    R x R LAPACK steps) on the oracle-backed engine, no GPU, against the real reference."""
+    import sidekit_amd as sk
+    from fake_engine import OracleEngine
+    from backend_case import run_backend_case
+    run_backend_case(sk, OracleEngine())
+
+
+def scipy_inv(a):
+    import scipy.linalg
+    return scipy.linalg.inv(a)
+
+
 def _pp_cases():
     g = golden("post_processing.npz")
     for i in range(int(g["n_cases"])):

@@ -13,6 +13,7 @@ derivative travels with the repo.  The recipe follows SURVEY.md Appendix A:
 
 Usage:  SIDEKIT=libsvm=false python3 -W ignore tools/gen_golden.py
 """
+import copy
 import os
 import sys
 import types
@@ -348,6 +349,88 @@ def gen_cosine(sidekit):
     print("cosine", sc.scoremat.shape, list(sc.modelset), list(sc.segset))
 
 
+def gen_backend(sidekit):
+    """i-vector back-end: StatServer covariance / LDA / WCCN / Mahalanobis matrices and whitening
+    (statserver.py:732-925, 1228-1245), mahalanobis_scoring and two_covariance_scoring (iv_scoring.py:109-205).
+    Speakers with 1..9 sessions, enrolment with repeated models (averaged by the scorers), an Ndx with a missing model
+    and a missing segment."""
+    rs = np.random.RandomState(99)
+    R, K = 10, 14
+    nsess = rs.randint(2, 10, size=K)
+    nsess[3] = 1                                          # a one-session speaker: zero within-class scatter
+    spk_mean = rs.randn(K, R) * 1.5
+    models, rows = [], []
+    for k in range(K):
+        for j in range(nsess[k]):
+            models.append("spk%02d" % k)
+            rows.append(spk_mean[k] + rs.randn(R) * rs.uniform(0.3, 1.0, size=R) + 0.7)
+    order = rs.permutation(len(models))                   # sessions of a speaker are not contiguous
+    models = [models[i] for i in order]
+    X = np.array([rows[i] for i in order])
+
+    def server(modelset, segset, stat1):
+        ss = sidekit.StatServer()
+        ss.modelset = np.array(modelset)
+        ss.segset = np.array(segset)
+        ss.start = np.empty(len(segset), "|O")
+        ss.stop = np.empty(len(segset), "|O")
+        ss.stat0 = np.ones((len(segset), 1))
+        ss.stat1 = np.array(stat1, dtype=np.float64)
+        return ss
+
+    segs = ["seg%03d" % i for i in range(len(models))]
+    dev = server(models, segs, X)
+    out = dict(R=R, modelset=dev.modelset, segset=dev.segset, stat1=dev.stat1.copy())
+    out["total_cov"] = dev.get_total_covariance_stat1()
+    out["within_cov"] = dev.get_within_covariance_stat1()
+    out["between_cov"] = dev.get_between_covariance_stat1()
+    out["lda_rank"] = 6
+    out["lda"] = dev.get_lda_matrix_stat1(6)
+    out["mahalanobis_matrix"] = dev.get_mahalanobis_matrix_stat1()
+    out["wccn_chol"] = dev.get_wccn_choleski_stat1()
+    mps = dev.mean_stat_per_model()
+    out["mean_per_model_modelset"] = mps.modelset
+    out["mean_per_model_stat0"] = mps.stat0
+    out["mean_per_model_stat1"] = mps.stat1
+    mu = dev.get_mean_stat1()
+    out["mu"] = mu
+    w = copy.deepcopy(dev)
+    w.whiten_stat1(mu, out["total_cov"])
+    out["whitened_full"] = w.stat1
+    w = copy.deepcopy(dev)
+    w.whiten_cholesky_stat1(mu, out["total_cov"])
+    out["whitened_chol"] = w.stat1
+    w = copy.deepcopy(dev)
+    w.whiten_stat1(mu, out["wccn_chol"], isSqrInvSigma=True)
+    out["whitened_presqrt"] = w.stat1
+
+    # scoring: enrolment sessions with repeated models, test segments, an Ndx with unknown entries
+    e_models = ["spk%02d" % k for k in (0, 1, 1, 2, 5, 5, 5, 7)]
+    enroll = server(e_models, ["e%d" % i for i in range(len(e_models))], spk_mean[[0, 1, 1, 2, 5, 5, 5, 7]]
+                    + 0.4 * rs.randn(len(e_models), R))
+    test = server(["t%d" % i for i in range(9)], ["t%d" % i for i in range(9)],
+                  spk_mean[rs.randint(0, K, size=9)] + 0.5 * rs.randn(9, R))
+    ndx = sidekit.Ndx()
+    ndx.modelset = np.array(["spk05", "spk01", "spkXX", "spk00", "spk07"])
+    ndx.segset = np.array(["t7", "t3", "tY", "t0", "t1", "t5", "t8"])
+    ndx.trialmask = rs.rand(5, 7) < 0.6
+    out.update(enroll_modelset=enroll.modelset, enroll_segset=enroll.segset, enroll_iv=enroll.stat1.copy(),
+               test_segset=test.segset, test_iv=test.stat1.copy(), ndx_modelset=ndx.modelset, ndx_segset=ndx.segset,
+               trialmask=ndx.trialmask)
+    sc = sidekit.iv_scoring.mahalanobis_scoring(copy.deepcopy(enroll), copy.deepcopy(test), ndx,
+                                                out["mahalanobis_matrix"])
+    out.update(maha_scoremat=sc.scoremat, maha_modelset=sc.modelset, maha_segset=sc.segset, maha_scoremask=sc.scoremask)
+    M_ns = out["mahalanobis_matrix"] + 0.05 * rs.randn(R, R)          # a non-symmetric matrix is legal input
+    out["maha_nonsym_matrix"] = M_ns
+    out["maha_nonsym_scoremat"] = sidekit.iv_scoring.mahalanobis_scoring(copy.deepcopy(enroll), copy.deepcopy(test),
+                                                                         ndx, M_ns).scoremat
+    sc = sidekit.iv_scoring.two_covariance_scoring(copy.deepcopy(enroll), copy.deepcopy(test), ndx,
+                                                   out["within_cov"], out["between_cov"])
+    out.update(twocov_scoremat=sc.scoremat, twocov_modelset=sc.modelset, twocov_segset=sc.segset)
+    np.savez_compressed(os.path.join(OUT, "iv_backend.npz"), **out)
+    print("backend", X.shape, out["lda"].shape, sc.scoremat.shape, list(sc.modelset))
+
+
 def gen_post_processing(sidekit):
     """FeaturesServer.post_processing (features_server.py:202-246) on a few synthetic sessions: the experiment's
     configuration (model_interface.py:45-52: RASTA + delta + double delta + cmvn, all frames kept) and the other
@@ -406,6 +489,9 @@ def gen_post_processing(sidekit):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "backend":
+        gen_backend(import_reference())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "cosine":
         gen_cosine(import_reference())
         return
@@ -426,6 +512,7 @@ def main():
         gen_stats_and_tv(sidekit, tmp)
     gen_gmm_scoring(sidekit)
     gen_cosine(sidekit)
+    gen_backend(sidekit)
     gen_post_processing(sidekit)
 
 
