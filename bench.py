@@ -363,7 +363,40 @@ def main():
         result["scoring"]["cosine"] = {"value": world * ne * ne / dtc, "unit": "trials/s",
                                        "workload": "cosine_scoring body, %d x %d i-vectors of rank 400 per GPU, float64" % (ne, ne),
                                        "f64_tflops": 2.0 * ne * ne * 400 / dtc / 1e12}
-        del iv_e, iv_t
+        # Mahalanobis scoring (iv_scoring.py:138-142): 4 rank-sized products, 2 cross-term GEMMs, 2 quadratic forms
+        Mm = torch.eye(400, dtype=torch.float64, device=dev) + 0.01 * torch.randn(400, 400, dtype=torch.float64, device=dev)
+        from importlib import import_module
+        ivs = import_module(sk.cosine_scoring.__module__)
+
+        def maha_all():
+            return ivs._pair_scores(eng, iv_e, iv_t, Mm, Mm, 0.5, -0.5, -0.5)
+        maha_all()
+        dtm, _ = timed(maha_all, 3)
+        dtm /= 3
+        result["scoring"]["mahalanobis"] = {"value": world * ne * ne / dtm, "unit": "trials/s",
+                                            "workload": "mahalanobis_scoring body, %d x %d i-vectors of rank 400 per GPU, float64" % (ne, ne),
+                                            "f64_tflops": (4.0 * ne * ne * 400 + 4.0 * ne * 400 * 400) / dtm / 1e12}
+        # WCCN / LDA within-class scatter (statserver.py:913-920): class means, centring, ONE float64 GEMM Xc'Xc
+        ns, nk = 50_000, 5_000
+        ss = sk.StatServer(engine=eng)
+        ss.modelset = np.array(["s%05d" % (i % nk) for i in range(ns)])
+        ss.segset = ss.modelset
+        ss.stat0 = np.ones((ns, 1))
+        ss.stat1 = np.random.RandomState(3).randn(ns, 400)
+
+        def wccn_scatter():
+            Xc = ss._class_centred(True)[2]
+            return eng.gram(Xc, alpha=1.0 / nk)
+        wccn_scatter()
+        eng.profile(True)
+        dtw, _ = timed(wccn_scatter, 2)
+        dtw /= 2
+        prof = eng.profile_read()
+        eng.profile(False)
+        result["scoring"]["wccn_scatter"] = {"value": world * ns / dtw, "unit": "i-vectors/s",
+                                             "workload": "within-class scatter of %d i-vectors (rank 400) of %d speakers, host upload included" % (ns, nk),
+                                             "kernels_ms_per_call": {k: round(v[1] / 2, 3) for k, v in sorted(prof.items())}}
+        del iv_e, iv_t, ss
 
     if "feat" in legs:
         # ---- Feature post-processing in front of the path (FeaturesServer.post_processing, features_server.py:202-246;

@@ -482,6 +482,26 @@ class HipEngine(object):
                                               self._ptr(a), float(ca), self._ptr(b), float(cb), self._stream()))
         return Sc
 
+    def gram(self, X, alpha=1.0):
+        """alpha X'X (R x R float64) of an S x R float64 device matrix.  R x R is a handful of output tiles (49 at
+        R = 400) while K = S is long, so the rows are cut into slices that run as one batched GEMM (about 1024
+        workgroups) and the slices' products are added in a fixed order (skm_class_sums over the slabs)."""
+        torch = self.torch
+        assert X.dim() == 2 and X.dtype == torch.float64 and X.is_contiguous()
+        S, R = X.shape
+        tiles = ((R + 63) // 64) ** 2
+        Z = min(-(-1024 // tiles), S // 1024)
+        if Z < 2:
+            return self.gemm(X, X, transA=True, alpha=alpha)
+        kc = S // Z
+        slabs = torch.empty((Z, R * R), dtype=torch.float64, device=self.device)
+        self._check(self.lib.skm_gemm(self.ctx, self.GEMM_F64_F64, self._ptr(X), self._ptr(X), self._ptr(slabs),
+                                      R, R, kc, R, R, R, 1, 0, 1.0, 0.0, Z, kc * R, kc * R, R * R, self._stream()))
+        if Z * kc < S:
+            rest = X[Z * kc:]
+            self.gemm(rest, rest, C=slabs[0].view(R, R), transA=True, beta=1.0)
+        return self.class_sums(slabs, np.array([0, Z], dtype=np.int64), alpha=alpha).view(R, R)
+
     def row_normalize_(self, X):
         """In-place length normalisation of the rows of a float64 device matrix (norm clipped at 1e-8)."""
         assert X.dim() == 2 and X.dtype == self.torch.float64 and X.is_contiguous()

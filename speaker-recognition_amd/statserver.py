@@ -342,13 +342,13 @@ class StatServer(object):
         eng = self.engine
         X = eng._f64_dev(self.stat1)
         Xc = eng.rows_center(X, Mu=eng.col_mean(X))
-        return eng.to_host(eng.gemm(Xc, Xc, transA=True, alpha=1.0 / self.stat1.shape[0]))
+        return eng.to_host(eng.gram(Xc, alpha=1.0 / self.stat1.shape[0]))
 
     def get_within_covariance_stat1(self):
         """statserver.py:810-826."""
         eng = self.engine
         Xc = self._class_centred(False)[2]
-        return eng.to_host(eng.gemm(Xc, Xc, transA=True, alpha=1.0 / self.stat1.shape[0]))
+        return eng.to_host(eng.gram(Xc, alpha=1.0 / self.stat1.shape[0]))
 
     def get_between_covariance_stat1(self):
         """statserver.py:828-848: sum_k n_k (m_k - mu)(m_k - mu)' / S."""
@@ -357,16 +357,16 @@ class StatServer(object):
         X = eng._f64_dev(self.stat1)
         means = eng.class_sums(X, off, src=order, mean=True)
         Mc = eng.rows_center(means, Mu=eng.col_mean(X), scale=np.sqrt(counts.astype(np.float64)))
-        return eng.to_host(eng.gemm(Mc, Mc, transA=True, alpha=1.0 / self.stat1.shape[0]))
+        return eng.to_host(eng.gram(Mc, alpha=1.0 / self.stat1.shape[0]))
 
     def get_lda_matrix_stat1(self, rank):
         """statserver.py:850-889 (scipy's eigh on the non-symmetric discrimination matrix, as the reference)."""
         import scipy.linalg
         eng = self.engine
         X, means, Xc, counts = self._class_centred(True)
-        Sw = eng.to_host(eng.gemm(Xc, Xc, transA=True))
+        Sw = eng.to_host(eng.gram(Xc))
         Mc = eng.rows_center(means, Mu=eng.col_mean(X))
-        Sb = eng.to_host(eng.gemm(Mc, Mc, transA=True))
+        Sb = eng.to_host(eng.gram(Mc))
         eigen_values, eigen_vectors = scipy.linalg.eigh(np.dot(Sb, scipy.linalg.inv(Sw)).transpose())
         idx = eigen_values.real.argsort()[-rank:][::-1]
         return eigen_vectors.real[:, idx]
@@ -381,7 +381,7 @@ class StatServer(object):
         import scipy.linalg
         eng = self.engine
         X, means, Xc, counts = self._class_centred(True)
-        WCCN = eng.to_host(eng.gemm(Xc, Xc, transA=True, alpha=1.0 / counts.shape[0]))
+        WCCN = eng.to_host(eng.gram(Xc, alpha=1.0 / counts.shape[0]))
         return scipy.linalg.cholesky(scipy.linalg.inv(WCCN)).T
 
     def mean_stat_per_model(self):

@@ -172,6 +172,9 @@ class OracleEngine(object):
             x = x * self._f64_dev(scale).numpy()[:, None]
         return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
 
+    def gram(self, X, alpha=1.0):
+        return torch.from_numpy(alpha * X.numpy().T.dot(X.numpy()))
+
     def row_dot(self, A, B):
         return torch.from_numpy((A.numpy() * B.numpy()).sum(axis=1))
 

@@ -62,3 +62,13 @@ def test_backend_reductions_ragged_vs_oracle(sk, eng):
     _close(sk.mahalanobis_scoring(e, t, ndx, M).scoremat, orc.mahalanobis_scores(E, T, M), 1e-11)
     B = orc.between_covariance(models, x)
     _close(sk.two_covariance_scoring(e, t, ndx, M, B).scoremat, orc.two_covariance_scores(E, T, M, B), 1e-10)
+
+
+def test_gram_split_over_rows_with_remainder(eng):
+    """S = 30 011 rows, R = 83: 4 output tiles -> the rows are cut into 29 slices of 1034 plus a 25-row remainder."""
+    rs = np.random.RandomState(8)
+    x = rs.randn(30011, 83) + 0.5
+    got = eng.to_host(eng.gram(eng._f64_dev(x), alpha=0.25))
+    _close(got, 0.25 * x.T.dot(x), 1e-12)
+    again = eng.to_host(eng.gram(eng._f64_dev(x), alpha=0.25))
+    np.testing.assert_array_equal(got, again)                   # fixed summation order
