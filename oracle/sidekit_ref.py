@@ -641,3 +641,31 @@ def two_covariance_scores(enroll_iv, test_iv, W, B):
         A = enroll_iv[i] + test_iv
         S[i] = np.sum(np.dot(A, G) * A, axis=1) - s3 - s2[i]
     return S
+
+
+def fast_plda_scores(enroll_iv, test_iv, mu, F, Sigma, p_known=0.0, scaling_factor=1.0):
+    """sidekit/iv_scoring.py:413-469 on already aligned, model-averaged i-vectors."""
+    e, t = enroll_iv - mu, test_iv - mu
+    inv_sigma = scipy.linalg.inv(Sigma)
+    eye = np.eye(F.shape[1])
+    K = F.T.dot(inv_sigma * scaling_factor).dot(F)
+    K1 = scipy.linalg.inv(K + eye)
+    K2 = scipy.linalg.inv(2 * K + eye)
+    cst = np.linalg.slogdet(K2)[1] / 2.0 - np.linalg.slogdet(K1)[1]
+    s_ac = F.dot(F.T)
+    s_tot = s_ac + Sigma
+    s_tot_inv = scipy.linalg.inv(s_tot)
+    tmp = np.linalg.inv(s_tot - s_ac.dot(s_tot_inv).dot(s_ac))
+    phi = s_tot_inv - tmp
+    psi = s_tot_inv.dot(s_ac).dot(tmp)
+    mp = 0.5 * np.einsum('ij, ji->i', e.dot(phi), e.T)
+    sp = 0.5 * np.einsum('ij, ji->i', t.dot(phi), t.T)
+    sc = (mp[:, None] + sp + cst + e.dot(psi).dot(t.T)) * scaling_factor
+    if p_known != 0:
+        N = sc.shape[0]
+        ex = np.exp(sc)
+        out = np.empty(sc.shape)
+        for i in range(N):
+            out[i] = sc[i] - np.log(p_known * ex[~(np.arange(N) == i)].sum(axis=0) / (N - 1) + (1 - p_known))
+        sc = out
+    return sc

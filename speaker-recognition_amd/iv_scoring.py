@@ -113,3 +113,61 @@ def two_covariance_scoring(enroll, test, ndx, W, B, check_missing=True):
     eng = enroll.engine
     s = _pair_scores(eng, eng._f64_dev(enroll.stat1), eng._f64_dev(test.stat1), G, G - H, 1.0, 1.0, 1.0)
     return _finish(eng.to_host(s), clean_ndx)
+
+
+def fast_PLDA_scoring(enroll, test, ndx, mu, F, Sigma, test_uncertainty=None, Vtrans=None, p_known=0.0,
+                      scaling_factor=1., check_missing=True):
+    """Simplified-PLDA log-likelihood ratios for all pairs (iv_scoring.py:364-471): 0.5 e'Phi e + 0.5 t'Phi t + e'Psi t +
+    constant.  Phi, Psi and the constant come from R x R host inverses as in the reference; the pair terms are a device
+    GEMM, two quadratic forms and skm_pair_combine.  The open-set correction (p_known != 0) is an element-wise pass
+    over the score matrix once it is on the host (the product this function returns).  `test_uncertainty` / `Vtrans`
+    are accepted and unused, as in the reference."""
+    import scipy.linalg
+    enroll_ctr = _unique_models(copy.deepcopy(enroll))
+    test_ctr = copy.deepcopy(test)
+    clean_ndx = _check_missing_model(enroll_ctr, test_ctr, ndx) if check_missing else ndx
+
+    invSigma = scipy.linalg.inv(Sigma)
+    I_spk = np.eye(F.shape[1], dtype='float')
+    K = F.T.dot(invSigma * scaling_factor).dot(F)
+    K1 = scipy.linalg.inv(K + I_spk)
+    K2 = scipy.linalg.inv(2 * K + I_spk)
+    plda_cst = np.linalg.slogdet(K2)[1] / 2.0 - np.linalg.slogdet(K1)[1]
+    Sigma_ac = np.dot(F, F.T)
+    Sigma_tot = Sigma_ac + Sigma
+    Sigma_tot_inv = scipy.linalg.inv(Sigma_tot)
+    Tmp = np.linalg.inv(Sigma_tot - Sigma_ac.dot(Sigma_tot_inv).dot(Sigma_ac))
+    Phi = Sigma_tot_inv - Tmp
+    Psi = Sigma_tot_inv.dot(Sigma_ac).dot(Tmp)
+
+    eng = enroll.engine
+    mu_dev = eng._f64_dev(np.asarray(mu, dtype=np.float64).reshape(1, -1))
+    E = eng.rows_center(eng._f64_dev(enroll_ctr.stat1), Mu=mu_dev)          # center_stat1 on i-vectors (stat0 = 1)
+    T = eng.rows_center(eng._f64_dev(test_ctr.stat1), Mu=mu_dev)
+    Phi_dev = eng._f64_dev(Phi)
+    model_part = eng.row_dot(eng.gemm(E, Phi_dev), E)
+    seg_part = eng.row_dot(eng.gemm(T, Phi_dev), T)
+    model_part += 2.0 * plda_cst                                            # 0.5 * (e'Phi e + 2 cst)
+    s = eng.gemm(eng.gemm(E, eng._f64_dev(Psi)), T, transB=True)
+    s = eng.to_host(eng.pair_combine_(s, model_part, seg_part, alpha=scaling_factor, ca=0.5 * scaling_factor,
+                                      cb=0.5 * scaling_factor))
+    if p_known != 0:
+        N = s.shape[0]
+        ex = np.exp(s)
+        s = s - np.log(p_known * (ex.sum(axis=0)[None, :] - ex) / (N - 1) + (1 - p_known))
+    return _finish(s, clean_ndx)
+
+
+def PLDA_scoring(enroll, test, ndx, mu, F, G, Sigma, test_uncertainty=None, Vtrans=None, p_known=0.0,
+                 scaling_factor=1., full_model=False):
+    """iv_scoring.py:208-263; only the simplified model (G unused) is on this path."""
+    assert isinstance(enroll, StatServer), 'First parameter should be a StatServer'
+    assert isinstance(test, StatServer), 'Second parameter should be a StatServer'
+    assert isinstance(ndx, Ndx), 'Third parameter should be an Ndx'
+    assert enroll.stat1.shape[1] == test.stat1.shape[1], 'I-vectors dimension mismatch'
+    assert enroll.stat1.shape[1] == F.shape[0], 'I-vectors and co-variance matrix dimension mismatch'
+    assert enroll.stat1.shape[1] == G.shape[0], 'I-vectors and co-variance matrix dimension mismatch'
+    if full_model:
+        raise NotImplementedError('full_PLDA_scoring (within-class factor G) is not on this path')
+    return fast_PLDA_scoring(enroll, test, ndx, mu, F, Sigma, test_uncertainty, Vtrans, p_known=p_known,
+                             scaling_factor=scaling_factor, check_missing=True)

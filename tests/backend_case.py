@@ -71,3 +71,14 @@ def run_backend_case(sk, eng, rtol=1e-10):
     sc = sk.two_covariance_scoring(enroll, test, ndx, g["within_cov"], g["between_cov"])
     assert list(sc.modelset) == list(g["twocov_modelset"]) and list(sc.segset) == list(g["twocov_segset"])
     _close(sc.scoremat, g["twocov_scoremat"], 10 * rtol)
+    for tag, kw in (("closed", dict()), ("open", dict(p_known=0.3)), ("scaled", dict(p_known=0.1, scaling_factor=0.8))):
+        enroll, test, ndx = trial_sets()
+        e0, t0 = enroll.stat1.copy(), test.stat1.copy()
+        sc = sk.fast_PLDA_scoring(enroll, test, ndx, g["plda_mu"], g["plda_F"], g["plda_Sigma"], **kw)
+        assert list(sc.modelset) == list(g["plda_modelset"]) and list(sc.segset) == list(g["plda_segset"])
+        _close(sc.scoremat, g["plda_%s_scoremat" % tag], 10 * rtol)
+        np.testing.assert_array_equal(enroll.stat1, e0)           # works on copies, like the reference
+        np.testing.assert_array_equal(test.stat1, t0)
+    enroll, test, ndx = trial_sets()
+    sc = sk.PLDA_scoring(enroll, test, ndx, g["plda_mu"], g["plda_F"], np.zeros((int(g["R"]), 1)), g["plda_Sigma"])
+    _close(sc.scoremat, g["plda_closed_scoremat"], 10 * rtol)

@@ -229,6 +229,9 @@ def test_iv_backend_oracle_vs_reference_golden():
     close(orc.mahalanobis_scores(e, t, g["mahalanobis_matrix"]), g["maha_scoremat"], rtol=1e-12)
     close(orc.mahalanobis_scores(e, t, g["maha_nonsym_matrix"]), g["maha_nonsym_scoremat"], rtol=1e-12)
     close(orc.two_covariance_scores(e, t, g["within_cov"], g["between_cov"]), g["twocov_scoremat"], rtol=1e-11)
+    for tag, kw in (("closed", dict()), ("open", dict(p_known=0.3)), ("scaled", dict(p_known=0.1, scaling_factor=0.8))):
+        close(orc.fast_plda_scores(e, t, g["plda_mu"], g["plda_F"], g["plda_Sigma"], **kw),
+              g["plda_%s_scoremat" % tag], rtol=1e-12)
 
 
 def test_iv_backend_host_logic_vs_reference_golden():

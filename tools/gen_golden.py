@@ -427,6 +427,17 @@ def gen_backend(sidekit):
     sc = sidekit.iv_scoring.two_covariance_scoring(copy.deepcopy(enroll), copy.deepcopy(test), ndx,
                                                    out["within_cov"], out["between_cov"])
     out.update(twocov_scoremat=sc.scoremat, twocov_modelset=sc.modelset, twocov_segset=sc.segset)
+    # fast_PLDA_scoring (iv_scoring.py:364-471): closed set, open set (p_known), a scaling factor
+    rank_f = 5
+    Fp = 0.8 * rs.randn(R, rank_f)
+    A = rs.randn(R, 3 * R)
+    Sig = A.dot(A.T) / (3 * R) + 0.2 * np.eye(R)
+    mu_p = dev.stat1.mean(axis=0)
+    out.update(plda_F=Fp, plda_Sigma=Sig, plda_mu=mu_p)
+    for tag, kw in (("closed", dict()), ("open", dict(p_known=0.3)), ("scaled", dict(p_known=0.1, scaling_factor=0.8))):
+        sc = sidekit.iv_scoring.fast_PLDA_scoring(copy.deepcopy(enroll), copy.deepcopy(test), ndx, mu_p, Fp, Sig, **kw)
+        out["plda_%s_scoremat" % tag] = sc.scoremat
+    out.update(plda_modelset=sc.modelset, plda_segset=sc.segset)
     np.savez_compressed(os.path.join(OUT, "iv_backend.npz"), **out)
     print("backend", X.shape, out["lda"].shape, sc.scoremat.shape, list(sc.modelset))
 
