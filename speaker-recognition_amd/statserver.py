@@ -419,7 +419,8 @@ class StatServer(object):
         self.stat1 = eng.to_host(eng.gemm(eng._f64_dev(self.stat1), eng._f64_dev(R)))
 
     # ------------------------------------------------------------------ MAP adaptation (feeds gmm_scoring)
-    # C*D element-wise float64 updates on already-reduced statistics: host, like the GMM M-step.
+    # C*D element-wise float64 updates on already-reduced statistics: host, like the GMM M-step; the per-model sums are
+    # device class sums.
     def get_model_stat0(self, mod_id):
         return self.stat0[self.modelset == mod_id, :]
 
@@ -435,12 +436,12 @@ class StatServer(object):
         out.stat1 = np.zeros((out.modelset.shape[0], self.stat1.shape[1]), dtype=STAT_TYPE)
         out.start = np.empty(out.segset.shape, '|O')
         out.stop = np.empty(out.segset.shape, '|O')
-        session_per_model = np.zeros(out.modelset.shape[0])
-        for idx, model in enumerate(out.modelset):
-            sel = self.modelset == model
-            out.stat0[idx, :] = self.stat0[sel, :].sum(axis=0)
-            out.stat1[idx, :] = self.stat1[sel, :].sum(axis=0)
-            session_per_model[idx] += sel.sum()
+        # one launch per statistic over the sessions sorted by model (skm_class_sums) instead of a masked sum per model
+        eng = self.engine
+        uniq, cls_sorted, order, counts, off = self._class_layout()
+        out.stat0[...] = eng.to_host(eng.class_sums(eng._f64_dev(self.stat0), off, src=order))
+        out.stat1[...] = eng.to_host(eng.class_sums(eng._f64_dev(self.stat1), off, src=order))
+        session_per_model = counts.astype(np.float64)
         return out, session_per_model
 
     def _map_means(self, ubm, stat0, stat1, alpha, norm):
