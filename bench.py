@@ -369,7 +369,7 @@ def main():
         ivs = import_module(sk.cosine_scoring.__module__)
 
         def maha_all():
-            return ivs._pair_scores(eng, iv_e, iv_t, Mm, Mm, 0.5, -0.5, -0.5)
+            return ivs._pair_scores(eng, iv_e, iv_t, Mm, None, 0.5, -0.5, -0.5)
         maha_all()
         dtm, _ = timed(maha_all, 3)
         dtm /= 3

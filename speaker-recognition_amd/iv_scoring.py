@@ -58,12 +58,15 @@ def _unique_models(enroll):
 
 
 def _pair_scores(eng, E, T, G, Q, alpha, ca, cb):
-    """alpha (e'G t + t'G e) + ca e'Q e + cb t'Q t for every (enrolment, test) pair: two R x R products per set, two
-    cross-term GEMMs accumulated into the score matrix, two row-wise quadratic forms."""
-    G, Q = eng._f64_dev(G), eng._f64_dev(Q)
+    """alpha (e'G t + t'G e) + ca e'Q e + cb t'Q t for every (enrolment, test) pair (Q = None: Q = G): two R x R
+    products per set, two cross-term GEMMs accumulated into the score matrix, two row-wise quadratic forms."""
+    G = eng._f64_dev(G)
     EG, TG = eng.gemm(E, G), eng.gemm(T, G)
-    qe = eng.row_dot(EG if Q is G else eng.gemm(E, Q), E)
-    qt = eng.row_dot(TG if Q is G else eng.gemm(T, Q), T)
+    if Q is None:
+        qe, qt = eng.row_dot(EG, E), eng.row_dot(TG, T)
+    else:
+        Q = eng._f64_dev(Q)
+        qe, qt = eng.row_dot(eng.gemm(E, Q), E), eng.row_dot(eng.gemm(T, Q), T)
     S = eng.gemm(EG, T, transB=True)
     S = eng.gemm(E, TG, C=S, transB=True, beta=1.0)
     return eng.pair_combine_(S, qe, qt, alpha=alpha, ca=ca, cb=cb)
@@ -89,8 +92,7 @@ def mahalanobis_scoring(enroll, test, ndx, m, check_missing=True):
     enroll = _unique_models(enroll)
     clean_ndx = _check_missing_model(enroll, test, ndx) if check_missing else ndx
     eng = enroll.engine
-    m = eng._f64_dev(m)
-    s = _pair_scores(eng, eng._f64_dev(enroll.stat1), eng._f64_dev(test.stat1), m, m, 0.5, -0.5, -0.5)
+    s = _pair_scores(eng, eng._f64_dev(enroll.stat1), eng._f64_dev(test.stat1), m, None, 0.5, -0.5, -0.5)
     return _finish(eng.to_host(s), clean_ndx)
 
 

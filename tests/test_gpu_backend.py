@@ -72,3 +72,35 @@ def test_gram_split_over_rows_with_remainder(eng):
     _close(got, 0.25 * x.T.dot(x), 1e-12)
     again = eng.to_host(eng.gram(eng._f64_dev(x), alpha=0.25))
     np.testing.assert_array_equal(got, again)                   # fixed summation order
+
+
+def test_backend_full_size_properties(sk, eng):
+    """BASELINE configs[4] size (50 000 i-vectors of rank 400, 5 000 speakers) through size-independent properties:
+    total = within + between covariance (law of total variance), WCCN factor W satisfies W W' = inverse of the mean
+    per-speaker scatter, Mahalanobis scores with the identity are -0.5 squared distances and vanish on the diagonal
+    of a set scored against itself, two-covariance scores of a set against itself are symmetric."""
+    rs = np.random.RandomState(11)
+    S, R, K = 50_000, 400, 5_000
+    spk = rs.randint(0, K, size=S)
+    spk[:K] = np.arange(K)                                        # every speaker has at least one session
+    x = rs.randn(K, R)[spk] * 1.5 + rs.randn(S, R) + 0.25
+    ss = _server(sk, eng, np.array(["s%04d" % k for k in spk]), np.array(["g%d" % i for i in range(S)]), x)
+    tot, wit, bet = ss.get_total_covariance_stat1(), ss.get_within_covariance_stat1(), ss.get_between_covariance_stat1()
+    _close(wit + bet, tot, 1e-11)
+    assert np.abs(tot - tot.T).max() <= 1e-13 * np.abs(tot).max()
+    W = ss.get_wccn_choleski_stat1()
+    X, means, Xc, counts = ss._class_centred(True)
+    scatter = eng.to_host(eng.gram(Xc, alpha=1.0 / K))
+    _close(W.dot(W.T).dot(scatter), np.eye(R), 1e-8)
+    n = 3000
+    sub = _server(sk, eng, ["m%d" % i for i in range(n)], ["m%d" % i for i in range(n)], x[:n])
+    ndx = sk.Ndx()
+    ndx.modelset, ndx.segset = sub.modelset.copy(), sub.segset.copy()
+    ndx.trialmask = np.ones((n, n), dtype=bool)
+    d = sk.mahalanobis_scoring(sub, sub, ndx, np.eye(R)).scoremat
+    sq = (x[:n] ** 2).sum(axis=1)
+    ref = -0.5 * (sq[:, None] + sq[None, :] - 2.0 * x[:n].dot(x[:n].T))
+    assert np.abs(d - ref).max() <= 1e-11 * np.abs(ref).max()
+    assert np.abs(np.diag(d)).max() <= 1e-10 * np.abs(ref).max()
+    tc = sk.two_covariance_scoring(sub, sub, ndx, wit, bet).scoremat
+    assert np.abs(tc - tc.T).max() <= 1e-10 * np.abs(tc).max()
