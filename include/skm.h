@@ -246,6 +246,23 @@ int skm_feat_postproc(void *ctx, const void *X_dev, int in_f64, long ldx, const 
                       int keep_all, void *out_dev, int out_f64, uint8_t *label_out_dev, int64_t *out_off_dev,
                       void *ws_dev, size_t ws_bytes, void *stream);
 
+/* Sliding-window normalisation 'cms_sliding' / 'cmvn_sliding' (sidekit/features_server.py:282-287 ->
+ * cep_sliding_norm, sidekit/frontend/normfeat.py:194-229) of a batch of sessions, after skm_feat_postproc with
+ * norm = 0 and keep_all = 1:
+ *   Y_dev      [rows][D] float64, the un-normalised frames; out_dev another [rows][D] buffer that starts as a copy
+ *   idx_dev    row of every labelled frame (ascending), coff_dev[S+1] = labelled frames before each session
+ *   a session with more than `win` labelled frames: labelled frame p gets (y - mean) [/ std] over the labelled
+ *   frames [c - win/2, c + win/2], c = p clipped to [win/2, n - win/2 - 1] (pandas rolling, centred, sample std;
+ *   edges replicated, normfeat.py:215-224); unlabelled frames keep their value
+ *   a session with at most `win` labelled frames: all its rows are copied from Yn_dev = the whole-session cms /
+ *   cmvn result of skm_feat_postproc (normfeat.py:206-210); Yn_dev may be NULL when no such session exists
+ *   chunk_sess_dev / chunk_p0_dev [nchunks] int32: work list, 128 positions per entry -- labelled positions of a
+ *   long session, frames of a short one.  win odd (301 in the reference), reduce = 1 for 'cmvn_sliding'. */
+int skm_feat_sliding_norm(void *ctx, const double *Y_dev, const double *Yn_dev, double *out_dev, int D,
+                          const int64_t *idx_dev, const int64_t *coff_dev, const int64_t *seg_off_dev,
+                          const int *chunk_sess_dev, const int *chunk_p0_dev, int nchunks, int win, int reduce,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

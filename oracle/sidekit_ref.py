@@ -530,12 +530,41 @@ def post_processing(feat, label, mask=None, rasta=False, delta=False, double_del
             stdev = np.std(feat[label, :], axis=0)
             feat -= mu
             feat /= stdev
+    elif feat_norm in ('cmvn_sliding', 'cms_sliding'):
+        cep_sliding_norm(feat, label, win=301, reduce=(feat_norm == 'cmvn_sliding'))
     elif feat_norm is not None:
         raise NotImplementedError(feat_norm)
     if not keep_all_features:
         feat = feat[label]
         label = label[label]
     return feat, label
+
+
+def cep_sliding_norm(feat, label, win=301, reduce=False):
+    """frontend/normfeat.py:194-229 as called by features_server.py:282-287 (center=True): rolling mean and sample
+    standard deviation (pandas, the reference's own dependency) over `win` LABELLED frames, centred, the first and last
+    win // 2 positions take the nearest full window; only the labelled frames change.  With at most `win` labelled
+    frames: whole-session cms / cmvn (every frame changes; normfeat.py:77-126)."""
+    import pandas
+    if np.sum(label) <= win:
+        if reduce:
+            if not label.sum() == 0:
+                mu, sd = np.mean(feat[label, :], axis=0), np.std(feat[label, :], axis=0)
+                feat -= mu
+                feat /= sd
+        else:
+            feat -= np.mean(feat[label, :], axis=0)
+        return
+    d_win = win // 2
+    r = pandas.DataFrame(feat[label, :]).rolling(window=win, center=True)
+    mean, std = r.mean().values, r.std().values
+    mean[0:d_win, :] = mean[d_win, :]
+    mean[-d_win:, :] = mean[-d_win - 1, :]
+    std[0:d_win, :] = std[d_win, :]
+    std[-d_win:, :] = std[-d_win - 1, :]
+    feat[label, :] -= mean
+    if reduce:
+        feat[label, :] /= std
 
 
 # ------------------------------------------------------------------ i-vector back-end (next row, SURVEY 8f rank 3)

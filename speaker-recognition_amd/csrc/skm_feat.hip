@@ -571,3 +571,83 @@ extern "C" int skm_feat_postproc(void *ctx_, const void *X_dev, int in_f64, long
     }
     return SKM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Sliding-window normalisation (features_server.py:282-287 -> frontend/normfeat.py:194-229): mean and sample
+// standard deviation over `win` LABELLED frames centred on each labelled frame, the first / last win/2 positions
+// take the nearest full window; only labelled frames change.  A session with at most `win` labelled frames takes
+// the whole-session cms / cmvn result Yn (computed by skm_feat_postproc) for ALL its frames.
+// One lane per (chunk of 128 positions, column): the window sums are built once per chunk (relative to a pivot
+// sample, so the variance does not cancel) and then slid by one frame per step.  Reads Y, writes out (another
+// buffer: windows reach into neighbouring chunks).  idx: row of every labelled frame, coff: labelled frames before
+// each session.  Float64, no atomics.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_feat_sliding(const double *__restrict__ Y, const double *__restrict__ Yn,
+                                                      double *__restrict__ out, int D, const int64_t *__restrict__ idx,
+                                                      const int64_t *__restrict__ coff, const int64_t *__restrict__ seg,
+                                                      const int *__restrict__ chunk_sess, const int *__restrict__ chunk_p0,
+                                                      int nchunks, int win, int reduce)
+{
+    const int lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (chunk >= nchunks) return;
+    const int s = chunk_sess[chunk];
+    const long p0 = chunk_p0[chunk];
+    const long n = coff[s + 1] - coff[s];
+    if (n <= win) {     // whole-session normalisation: p0 counts frames of the session
+        const long r0 = seg[s] + p0;
+        const long r1 = (r0 + 128 < seg[s + 1]) ? r0 + 128 : seg[s + 1];
+        for (long r = r0; r < r1; ++r)
+            for (int j = lane; j < D; j += 64) out[r * D + j] = Yn[r * D + j];
+        return;
+    }
+    const int64_t *ix = idx + coff[s];
+    const long dw = win / 2;
+    const long p1 = (p0 + 128 < n) ? p0 + 128 : n;
+    const double w = (double)win;
+    for (int j = lane; j < D; j += 64) {
+        long c = p0 < dw ? dw : (p0 > n - dw - 1 ? n - dw - 1 : p0);
+        const double pivot = Y[ix[c - dw] * D + j];
+        double sum = 0.0, ssq = 0.0;
+        for (long q = c - dw; q <= c + dw; ++q) {
+            const double v = Y[ix[q] * D + j] - pivot;
+            sum += v;
+            ssq += v * v;
+        }
+        for (long p = p0; p < p1; ++p) {
+            const long cn = p < dw ? dw : (p > n - dw - 1 ? n - dw - 1 : p);
+            if (cn != c) {      // the window moves by one labelled frame
+                const double vin = Y[ix[cn + dw] * D + j] - pivot;
+                const double vout = Y[ix[c - dw] * D + j] - pivot;
+                sum += vin - vout;
+                ssq += vin * vin - vout * vout;
+                c = cn;
+            }
+            const long r = ix[p];
+            double v = Y[r * D + j] - (pivot + sum / w);
+            if (reduce) {
+                double var = (ssq - sum * sum / w) / (w - 1.0);
+                if (var < 0.0) var = 0.0;
+                v = v / sqrt(var);
+            }
+            out[r * D + j] = v;
+        }
+    }
+}
+
+extern "C" int skm_feat_sliding_norm(void *ctx_, const double *Y, const double *Yn, double *out, int D,
+                                     const int64_t *idx, const int64_t *coff, const int64_t *seg_off,
+                                     const int *chunk_sess, const int *chunk_p0, int nchunks, int win, int reduce,
+                                     void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && D > 0 && nchunks >= 0 && win >= 3 && (win & 1) && Y && out && Y != out && coff && seg_off &&
+                    (nchunks == 0 || (chunk_sess && chunk_p0)),
+                "skm_feat_sliding_norm: bad argument");
+    if (nchunks == 0) return SKM_OK;
+    SkmProfScope ps(ctx, "k_feat_sliding", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_feat_sliding, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Y, Yn, out,
+                       D, idx, coff, seg_off, chunk_sess, chunk_p0, nchunks, win, reduce);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}

@@ -16,8 +16,8 @@ Post-processing (the step in front of the path) runs on the
 skm_feat_postproc: column mask, RASTA, delta / double delta, cms / cmvn, VAD selection -- the
 configuration of the reference's experiments (model_interface.py:45-52) included.  `load_batch`
 post-processes many sessions in one launch and leaves the frames in HBM for the statistics kernels.
-Not covered: 'stg' (broken in the reference: float slice indices, frontend/normfeat.py:166), the
-sliding-window normalisations, dct_pca / sdc / context / traps.
+Not covered: 'stg' (broken in the reference: float slice indices, frontend/normfeat.py:166),
+dct_pca / sdc / context / traps.
 """
 import re
 
@@ -93,8 +93,6 @@ class FeaturesServer(object):
             if self.feat_norm == 'stg':
                 # the reference raises here as well (float slice indices, frontend/normfeat.py:166)
                 raise TypeError("slice indices must be integers or None or have an __index__ method")
-            if self.feat_norm in ('cmvn_sliding', 'cms_sliding'):
-                raise NotImplementedError("sliding-window normalisation is outside the device post-processing path")
             norm = 0                                          # features_server.py:288-289: warning, no normalisation
         else:
             norm = _NORMS[self.feat_norm]
@@ -110,9 +108,36 @@ class FeaturesServer(object):
         if self.rasta and seg.size > 1 and (np.diff(seg) < 3).any():
             # features_server.py:322: cep[2, :] of a session with fewer than three frames
             raise IndexError("index 2 is out of bounds: RASTA needs at least 3 frames per session")
-        return self.engine.feat_postproc(X, seg, label=label, cols=self.mask, rasta=self.rasta, ndelta=ndelta,
-                                         delta_filter=self.delta_filter, norm=norm, global_mean=global_mean,
-                                         global_std=global_std, keep_all=keep_all, out_dtype=out_dtype)
+        eng = self.engine
+        if self.feat_norm in ('cmvn_sliding', 'cms_sliding'):
+            return self._sliding(X, seg, label, keep_all, ndelta, out_dtype)
+        return eng.feat_postproc(X, seg, label=label, cols=self.mask, rasta=self.rasta, ndelta=ndelta,
+                                 delta_filter=self.delta_filter, norm=norm, global_mean=global_mean,
+                                 global_std=global_std, keep_all=keep_all, out_dtype=out_dtype)
+
+    def _sliding(self, X, seg, label, keep_all, ndelta, out_dtype, win=301):
+        """'cmvn_sliding' / 'cms_sliding' (features_server.py:282-287; global statistics are not used by them):
+        mask / RASTA / deltas without normalisation for every frame, then cep_sliding_norm on the device; sessions
+        with at most `win` labelled frames take the whole-session cmvn / cms pass instead (normfeat.py:206-210)."""
+        eng = self.engine
+        torch = eng.torch
+        reduce = self.feat_norm == 'cmvn_sliding'
+        common = dict(label=label, cols=self.mask, rasta=self.rasta, ndelta=ndelta, delta_filter=self.delta_filter,
+                      keep_all=True, out_dtype=torch.float64)
+        Y, lab_out, _ = eng.feat_postproc(X, seg, norm=0, **common)
+        lab_host = lab_out.cpu().numpy().astype(bool)
+        before = np.concatenate([[0], np.cumsum(lab_host, dtype=np.int64)])
+        Yn = None
+        if (np.diff(before[seg]) <= win).any():
+            Yn = eng.feat_postproc(X, seg, norm=2 if reduce else 1, **common)[0]
+        out, idx_dev, coff = eng.feat_sliding_norm(Y, Yn, lab_host, seg, win=win, reduce=reduce)
+        if not keep_all:
+            out = eng.rows_center(out, src=idx_dev)                  # the labelled frames, compacted
+            lab_out = torch.ones(out.shape[0], dtype=torch.uint8, device=eng.device)
+            out_off = torch.from_numpy(coff).to(eng.device)
+        else:
+            out_off = torch.from_numpy(seg - seg[0]).to(eng.device)
+        return out.to(out_dtype or torch.float32), lab_out, out_off
 
     def post_processing(self, feat, label, global_mean=None, global_std=None):
         """One session (features_server.py:202-246).  NumPy in -> NumPy float64 out; a device tensor in ->

@@ -176,3 +176,54 @@ def test_accumulate_stat_from_raw_frames_on_device(sk):
     ss2.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(12))
     assert np.abs(ss2.stat0 - ss.stat0).max() / np.abs(s0).max() < 1e-6
     assert np.abs(ss2.stat1 - ss.stat1).max() / np.abs(s1).max() < 1e-6
+
+
+def _sliding_cases():
+    g = golden("post_processing_sliding.npz")
+    for i in range(int(g["n_cases"])):
+        o = g["case%d_opt" % i]
+        kw = dict(mask=None, rasta=bool(o[0]), delta=bool(o[1]), double_delta=bool(o[2]),
+                  feat_norm={3: "cms_sliding", 4: "cmvn_sliding"}[int(o[3])], keep_all_features=bool(o[4]))
+        yield i, g["case%d_x" % i], g["case%d_label" % i], kw, g["case%d_feat" % i], g["case%d_lab" % i]
+
+
+def test_sliding_normalisation_vs_reference_golden(sk):
+    """'cmvn_sliding' / 'cms_sliding' (features_server.py:282-287 -> normfeat.py:194-229) of the real reference:
+    long sessions (rolling statistics over 301 labelled frames), sessions with at most 301 labelled frames
+    (whole-session fallback; 301 and 302 labelled frames sit on either side of the switch)."""
+    n = 0
+    for i, x, label, kw, feat, lab in _sliding_cases():
+        f, l = server(sk, kw).post_processing(x.copy(), label.copy())
+        assert f.dtype == np.float64 and l.dtype == bool
+        assert np.array_equal(l, lab), i
+        check(f, feat, 1e-8)
+        n += 1
+    assert n == 7
+
+
+@pytest.mark.parametrize("keep_all", [True, False])
+@pytest.mark.parametrize("norm", ["cmvn_sliding", "cms_sliding"])
+def test_sliding_normalisation_batch_vs_oracle(sk, keep_all, norm):
+    """A batch of long, short, unlabelled and chunk-boundary sessions in one launch (load_batch): every session equals
+    the oracle run on it alone."""
+    rs = np.random.RandomState(21)
+    lens = [1500, 40, 302, 701, 3, 2048, 429]
+    kw = dict(mask=None, rasta=False, delta=True, double_delta=False, feat_norm=norm, keep_all_features=keep_all)
+    fs = server(sk, kw)
+    want, want_lab = [], []
+    for k, T in enumerate(lens):
+        x = 2.0 * rs.randn(T, 6) + 4.0 * rs.randn(1, 6) + np.cumsum(0.2 * rs.randn(T, 6), axis=0)
+        lab = rs.rand(T) > (0.25 if k != 3 else 0.0)
+        if k == 1:
+            lab[:] = True
+        fs.add("s%d" % k, x, lab)
+        f, l = orc.post_processing(x.copy(), lab.copy(), delta=True, feat_norm=norm, keep_all_features=keep_all)
+        want.append(f)
+        want_lab.append(l)
+    X, off, labels = fs.load_batch(["s%d" % k for k in range(len(lens))])
+    X, labels = X.cpu().numpy(), labels.cpu().numpy().astype(bool)
+    assert off[-1] == X.shape[0] == sum(w.shape[0] for w in want)
+    for k in range(len(lens)):
+        assert off[k + 1] - off[k] == want[k].shape[0], k
+        assert np.array_equal(labels[off[k]:off[k + 1]], want_lab[k])
+        check(X[off[k]:off[k + 1]], want[k].astype(np.float32), 2e-6)

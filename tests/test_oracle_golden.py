@@ -243,6 +243,24 @@ def test_iv_backend_host_logic_vs_reference_golden():
     run_backend_case(sk, OracleEngine())
 
 
+def _sliding_cases():
+    g = golden("post_processing_sliding.npz")
+    for i in range(int(g["n_cases"])):
+        o = g["case%d_opt" % i]
+        kw = dict(rasta=bool(o[0]), delta=bool(o[1]), double_delta=bool(o[2]),
+                  feat_norm={3: "cms_sliding", 4: "cmvn_sliding"}[int(o[3])], keep_all_features=bool(o[4]))
+        yield i, kw, g["case%d_x" % i], g["case%d_label" % i], g["case%d_feat" % i], g["case%d_lab" % i]
+
+
+def test_sliding_normalisation_oracle_vs_reference_golden():
+    """features_server.py:282-287 -> frontend/normfeat.py:194-229 (real reference, tools/gen_golden.py gen_sliding)."""
+    for i, kw, x, label, feat, lab in _sliding_cases():
+        f, l = orc.post_processing(x.copy(), label.copy(), **kw)
+        assert f.shape == feat.shape, i
+        np.testing.assert_array_equal(l, lab)
+        close(f, feat, rtol=1e-12)
+
+
 def scipy_inv(a):
     import scipy.linalg
     return scipy.linalg.inv(a)

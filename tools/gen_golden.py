@@ -498,8 +498,51 @@ def gen_post_processing(sidekit):
     np.savez_compressed(os.path.join(OUT, "post_processing.npz"), **out)
 
 
+def gen_sliding(sidekit):
+    """FeaturesServer.post_processing with feat_norm 'cmvn_sliding' / 'cms_sliding' (features_server.py:282-287 ->
+    frontend/normfeat.py:194-229: pandas rolling mean / sample std over 301 labelled frames, edges replicated;
+    sessions with at most 301 labelled frames fall back to whole-session cmvn / cms)."""
+    rs = np.random.RandomState(4242)
+    out, n = {}, 0
+    cases = [
+        dict(rasta=False, delta=True, double_delta=False, feat_norm="cmvn_sliding", keep_all_features=True, T=900, D=5),
+        dict(rasta=True, delta=False, double_delta=False, feat_norm="cms_sliding", keep_all_features=False, T=700, D=4),
+        dict(rasta=False, delta=False, double_delta=False, feat_norm="cmvn_sliding", keep_all_features=False, T=1203, D=3),
+        dict(rasta=False, delta=True, double_delta=True, feat_norm="cmvn_sliding", keep_all_features=True, T=350, D=3),
+        dict(rasta=False, delta=False, double_delta=False, feat_norm="cms_sliding", keep_all_features=True, T=120, D=2),
+        dict(rasta=False, delta=False, double_delta=False, feat_norm="cmvn_sliding", keep_all_features=True, T=302, D=2,
+             all_speech=True),
+        dict(rasta=False, delta=False, double_delta=False, feat_norm="cmvn_sliding", keep_all_features=True, T=301, D=2,
+             all_speech=True),
+    ]
+    for c in cases:
+        T, D = c["T"], c["D"]
+        x = 3.0 * rs.randn(T, D) + 5.0 * rs.randn(1, D) + np.cumsum(0.3 * rs.randn(T, D), axis=0)
+        label = rs.rand(T) > 0.3
+        if c.get("all_speech"):
+            label[:] = True
+        fs = sidekit.FeaturesServer(dataset_list=["cep"], feat_norm=c["feat_norm"], delta=c["delta"],
+                                    double_delta=c["double_delta"], rasta=c["rasta"],
+                                    keep_all_features=c["keep_all_features"])
+        feat, lab = fs.post_processing(x.copy(), label.copy())
+        out["case%d_opt" % n] = np.array([int(c["rasta"]), int(c["delta"]), int(c["double_delta"]),
+                                          {"cms_sliding": 3, "cmvn_sliding": 4}[c["feat_norm"]],
+                                          int(c["keep_all_features"])])
+        out["case%d_x" % n] = x
+        out["case%d_label" % n] = label
+        out["case%d_feat" % n] = np.asarray(feat)
+        out["case%d_lab" % n] = np.asarray(lab)
+        print("sliding case", n, c, "->", np.asarray(feat).shape, int(label.sum()), "labelled")
+        n += 1
+    out["n_cases"] = np.array(n)
+    np.savez_compressed(os.path.join(OUT, "post_processing_sliding.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "sliding":
+        gen_sliding(import_reference())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "backend":
         gen_backend(import_reference())
         return
@@ -524,6 +567,7 @@ def main():
     gen_gmm_scoring(sidekit)
     gen_cosine(sidekit)
     gen_backend(sidekit)
+    gen_sliding(sidekit)
     gen_post_processing(sidekit)
 
 
