@@ -439,6 +439,21 @@ def main():
                 if name.startswith("k_feat_walk<2, 1, 1"):
                     result["feat"]["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
                     result["feat"]["roofline"]["traffic_source"] = "profiles/r1_pmc_feat.json (FETCH_SIZE x2 + WRITE_SIZE)"
+        # 'cmvn_sliding' on the same batch (features_server.py:282-287): un-normalised pass in float64, rolling
+        # statistics over 301 labelled frames, compaction; the label vector crosses PCIe once to build the work list
+        fsl = sk.FeaturesServer(feat_norm="cmvn_sliding", delta=True, double_delta=True, rasta=True,
+                                keep_all_features=False, engine=eng)
+
+        def feat_sliding():
+            return fsl._post_process_device(raw, segf, vad, False)
+        feat_sliding()
+        eng.profile(True)
+        dts, _ = timed(feat_sliding, 2)
+        dts /= 2
+        prof = eng.profile_read()
+        eng.profile(False)
+        result["feat"]["cmvn_sliding"] = {"value": world * Sf * Lf / dts, "unit": "frames/s",
+                                          "kernels_ms_per_call": {k: round(v[1] / 2, 3) for k, v in sorted(prof.items())}}
         del raw, vad, fo
 
     if "tv" in legs:

@@ -256,12 +256,12 @@ int skm_feat_postproc(void *ctx, const void *X_dev, int in_f64, long ldx, const 
  *   edges replicated, normfeat.py:215-224); unlabelled frames keep their value
  *   a session with at most `win` labelled frames: all its rows are copied from Yn_dev = the whole-session cms /
  *   cmvn result of skm_feat_postproc (normfeat.py:206-210); Yn_dev may be NULL when no such session exists
- *   chunk_sess_dev / chunk_p0_dev [nchunks] int32: work list, 128 positions per entry -- labelled positions of a
+ *   chunk_sess_dev / chunk_p0_dev [nchunks] int32: work list, chunk_len positions per entry -- labelled positions of a
  *   long session, frames of a short one.  win odd (301 in the reference), reduce = 1 for 'cmvn_sliding'. */
 int skm_feat_sliding_norm(void *ctx, const double *Y_dev, const double *Yn_dev, double *out_dev, int D,
                           const int64_t *idx_dev, const int64_t *coff_dev, const int64_t *seg_off_dev,
-                          const int *chunk_sess_dev, const int *chunk_p0_dev, int nchunks, int win, int reduce,
-                          void *stream);
+                          const int *chunk_sess_dev, const int *chunk_p0_dev, int nchunks, int chunk_len, int win,
+                          int reduce, void *stream);
 
 #ifdef __cplusplus
 }

@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void k_feat_sliding(const double *__restrict__
                                                       double *__restrict__ out, int D, const int64_t *__restrict__ idx,
                                                       const int64_t *__restrict__ coff, const int64_t *__restrict__ seg,
                                                       const int *__restrict__ chunk_sess, const int *__restrict__ chunk_p0,
-                                                      int nchunks, int win, int reduce)
+                                                      int nchunks, int chunk_len, int win, int reduce)
 {
     const int lane = threadIdx.x & 63;
     const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -596,14 +596,14 @@ __global__ __launch_bounds__(256) void k_feat_sliding(const double *__restrict__
     const long n = coff[s + 1] - coff[s];
     if (n <= win) {     // whole-session normalisation: p0 counts frames of the session
         const long r0 = seg[s] + p0;
-        const long r1 = (r0 + 128 < seg[s + 1]) ? r0 + 128 : seg[s + 1];
+        const long r1 = (r0 + chunk_len < seg[s + 1]) ? r0 + chunk_len : seg[s + 1];
         for (long r = r0; r < r1; ++r)
             for (int j = lane; j < D; j += 64) out[r * D + j] = Yn[r * D + j];
         return;
     }
     const int64_t *ix = idx + coff[s];
     const long dw = win / 2;
-    const long p1 = (p0 + 128 < n) ? p0 + 128 : n;
+    const long p1 = (p0 + chunk_len < n) ? p0 + chunk_len : n;
     const double w = (double)win;
     for (int j = lane; j < D; j += 64) {
         long c = p0 < dw ? dw : (p0 > n - dw - 1 ? n - dw - 1 : p0);
@@ -637,17 +637,17 @@ __global__ __launch_bounds__(256) void k_feat_sliding(const double *__restrict__
 
 extern "C" int skm_feat_sliding_norm(void *ctx_, const double *Y, const double *Yn, double *out, int D,
                                      const int64_t *idx, const int64_t *coff, const int64_t *seg_off,
-                                     const int *chunk_sess, const int *chunk_p0, int nchunks, int win, int reduce,
-                                     void *stream)
+                                     const int *chunk_sess, const int *chunk_p0, int nchunks, int chunk_len, int win,
+                                     int reduce, void *stream)
 {
     SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
-    SKM_REQUIRE(ctx && D > 0 && nchunks >= 0 && win >= 3 && (win & 1) && Y && out && Y != out && coff && seg_off &&
+    SKM_REQUIRE(ctx && D > 0 && nchunks >= 0 && chunk_len > 0 && win >= 3 && (win & 1) && Y && out && Y != out && coff && seg_off &&
                     (nchunks == 0 || (chunk_sess && chunk_p0)),
                 "skm_feat_sliding_norm: bad argument");
     if (nchunks == 0) return SKM_OK;
     SkmProfScope ps(ctx, "k_feat_sliding", (hipStream_t)stream);
     hipLaunchKernelGGL(k_feat_sliding, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Y, Yn, out,
-                       D, idx, coff, seg_off, chunk_sess, chunk_p0, nchunks, win, reduce);
+                       D, idx, coff, seg_off, chunk_sess, chunk_p0, nchunks, chunk_len, win, reduce);
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }

@@ -125,12 +125,10 @@ class FeaturesServer(object):
         common = dict(label=label, cols=self.mask, rasta=self.rasta, ndelta=ndelta, delta_filter=self.delta_filter,
                       keep_all=True, out_dtype=torch.float64)
         Y, lab_out, _ = eng.feat_postproc(X, seg, norm=0, **common)
-        lab_host = lab_out.cpu().numpy().astype(bool)
-        before = np.concatenate([[0], np.cumsum(lab_host, dtype=np.int64)])
-        Yn = None
-        if (np.diff(before[seg]) <= win).any():
-            Yn = eng.feat_postproc(X, seg, norm=2 if reduce else 1, **common)[0]
-        out, idx_dev, coff = eng.feat_sliding_norm(Y, Yn, lab_host, seg, win=win, reduce=reduce)
+        # the whole-session pass is only run when some session has at most `win` labelled frames
+        out, idx_dev, coff = eng.feat_sliding_norm(
+            Y, lambda: eng.feat_postproc(X, seg, norm=2 if reduce else 1, **common)[0], lab_out, seg, win=win,
+            reduce=reduce)
         if not keep_all:
             out = eng.rows_center(out, src=idx_dev)                  # the labelled frames, compacted
             lab_out = torch.ones(out.shape[0], dtype=torch.uint8, device=eng.device)
