@@ -72,6 +72,25 @@ class OracleEngine(object):
         out = torch.from_numpy(np.vstack(feats)).to(out_dtype or torch.float32)
         return out, torch.from_numpy(np.concatenate(labs).astype(np.uint8)), torch.from_numpy(np.array(rows))
 
+    def feat_sliding_norm(self, Y, Yn, label, seg_host, win=301, reduce=False):
+        """Oracle cep_sliding_norm (sidekit/frontend/normfeat.py:194-229) session by session; same contract as
+        HipEngine.feat_sliding_norm (the whole-session fallback is taken from Yn as the device kernel does)."""
+        y = Y.numpy().copy()
+        lab = (label.numpy() if isinstance(label, torch.Tensor) else np.asarray(label)).astype(bool)
+        seg = np.asarray(seg_host, dtype=np.int64)
+        n = np.array([lab[seg[i]:seg[i + 1]].sum() for i in range(seg.size - 1)], dtype=np.int64)
+        if callable(Yn):
+            Yn = Yn() if (n <= win).any() else None
+        for i in range(seg.size - 1):
+            a, b = seg[i], seg[i + 1]
+            if n[i] <= win:
+                y[a:b] = Yn.numpy()[a:b]
+            else:
+                blk = y[a:b]
+                orc.cep_sliding_norm(blk, lab[a:b], win=win, reduce=reduce)
+        return (torch.from_numpy(y), torch.from_numpy(np.flatnonzero(lab[:seg[-1]]).astype(np.int64)),
+                np.concatenate([[0], np.cumsum(n)]).astype(np.int64))
+
     def moments(self, X):
         x = X.numpy().astype(np.float64)
         return torch.from_numpy(np.concatenate([x.sum(0), (x ** 2).sum(0)]))

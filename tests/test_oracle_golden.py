@@ -261,6 +261,19 @@ def test_sliding_normalisation_oracle_vs_reference_golden():
         close(f, feat, rtol=1e-12)
 
 
+def test_sliding_normalisation_host_logic_vs_reference_golden():
+    """FeaturesServer._sliding (un-normalised pass, lazy whole-session pass, compaction, dtypes) on the oracle-backed
+    engine, no GPU, against the real reference."""
+    import sidekit_amd as sk
+    from fake_engine import OracleEngine
+    for i, kw, x, label, feat, lab in _sliding_cases():
+        fs = sk.FeaturesServer(engine=OracleEngine(), **kw)
+        f, l = fs.post_processing(x.copy(), label.copy())
+        assert f.dtype == np.float64 and f.shape == feat.shape, i
+        np.testing.assert_array_equal(l, lab)
+        close(f, feat, rtol=1e-12)
+
+
 def scipy_inv(a):
     import scipy.linalg
     return scipy.linalg.inv(a)
