@@ -249,7 +249,11 @@ int skm_feat_postproc(void *ctx, const void *X_dev, int in_f64, long ldx, const 
 /* Sliding-window normalisation 'cms_sliding' / 'cmvn_sliding' (sidekit/features_server.py:282-287 ->
  * cep_sliding_norm, sidekit/frontend/normfeat.py:194-229) of a batch of sessions, after skm_feat_postproc with
  * norm = 0 and keep_all = 1:
- *   Y_dev      [rows][D] float64, the un-normalised frames; out_dev another [rows][D] buffer that starts as a copy
+ *   Y_dev      [rows][D] float64, the un-normalised frames
+ *   compact=0: out_dev is another [rows][D] float64 buffer (out_f64 = 1) that starts as a copy of Y
+ *   compact=1: out_dev is [labelled frames][D], float32 or float64: frame selection (features_server.py:241-244)
+ *              fused in, row of labelled frame p of session s = coff[s] + p; chunk entries of a short session then
+ *              count labelled positions too
  *   idx_dev    row of every labelled frame (ascending), coff_dev[S+1] = labelled frames before each session
  *   a session with more than `win` labelled frames: labelled frame p gets (y - mean) [/ std] over the labelled
  *   frames [c - win/2, c + win/2], c = p clipped to [win/2, n - win/2 - 1] (pandas rolling, centred, sample std;
@@ -258,7 +262,7 @@ int skm_feat_postproc(void *ctx, const void *X_dev, int in_f64, long ldx, const 
  *   cmvn result of skm_feat_postproc (normfeat.py:206-210); Yn_dev may be NULL when no such session exists
  *   chunk_sess_dev / chunk_p0_dev [nchunks] int32: work list, chunk_len positions per entry -- labelled positions of a
  *   long session, frames of a short one.  win odd (301 in the reference), reduce = 1 for 'cmvn_sliding'. */
-int skm_feat_sliding_norm(void *ctx, const double *Y_dev, const double *Yn_dev, double *out_dev, int D,
+int skm_feat_sliding_norm(void *ctx, const double *Y_dev, const double *Yn_dev, void *out_dev, int out_f64, int compact, int D,
                           const int64_t *idx_dev, const int64_t *coff_dev, const int64_t *seg_off_dev,
                           const int *chunk_sess_dev, const int *chunk_p0_dev, int nchunks, int chunk_len, int win,
                           int reduce, void *stream);

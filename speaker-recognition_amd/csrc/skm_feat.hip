@@ -582,8 +582,10 @@ extern "C" int skm_feat_postproc(void *ctx_, const void *X_dev, int in_f64, long
 // buffer: windows reach into neighbouring chunks).  idx: row of every labelled frame, coff: labelled frames before
 // each session.  Float64, no atomics.
 // ------------------------------------------------------------------------------------------------
+template <typename TO>
 __global__ __launch_bounds__(256) void k_feat_sliding(const double *__restrict__ Y, const double *__restrict__ Yn,
-                                                      double *__restrict__ out, int D, const int64_t *__restrict__ idx,
+                                                      TO *__restrict__ out, int compact, int D,
+                                                      const int64_t *__restrict__ idx,
                                                       const int64_t *__restrict__ coff, const int64_t *__restrict__ seg,
                                                       const int *__restrict__ chunk_sess, const int *__restrict__ chunk_p0,
                                                       int nchunks, int chunk_len, int win, int reduce)
@@ -594,11 +596,18 @@ __global__ __launch_bounds__(256) void k_feat_sliding(const double *__restrict__
     const int s = chunk_sess[chunk];
     const long p0 = chunk_p0[chunk];
     const long n = coff[s + 1] - coff[s];
+    if (n <= win && compact) {      // whole-session normalisation, labelled frames only
+        const int64_t *ixs = idx + coff[s];
+        const long pe = (p0 + chunk_len < n) ? p0 + chunk_len : n;
+        for (long p = p0; p < pe; ++p)
+            for (int j = lane; j < D; j += 64) out[(coff[s] + p) * D + j] = (TO)Yn[ixs[p] * D + j];
+        return;
+    }
     if (n <= win) {     // whole-session normalisation: p0 counts frames of the session
         const long r0 = seg[s] + p0;
         const long r1 = (r0 + chunk_len < seg[s + 1]) ? r0 + chunk_len : seg[s + 1];
         for (long r = r0; r < r1; ++r)
-            for (int j = lane; j < D; j += 64) out[r * D + j] = Yn[r * D + j];
+            for (int j = lane; j < D; j += 64) out[r * D + j] = (TO)Yn[r * D + j];
         return;
     }
     const int64_t *ix = idx + coff[s];
@@ -630,24 +639,29 @@ __global__ __launch_bounds__(256) void k_feat_sliding(const double *__restrict__
                 if (var < 0.0) var = 0.0;
                 v = v / sqrt(var);
             }
-            out[r * D + j] = v;
+            out[(compact ? coff[s] + p : r) * D + j] = (TO)v;
         }
     }
 }
 
-extern "C" int skm_feat_sliding_norm(void *ctx_, const double *Y, const double *Yn, double *out, int D,
+extern "C" int skm_feat_sliding_norm(void *ctx_, const double *Y, const double *Yn, void *out, int out_f64, int compact, int D,
                                      const int64_t *idx, const int64_t *coff, const int64_t *seg_off,
                                      const int *chunk_sess, const int *chunk_p0, int nchunks, int chunk_len, int win,
                                      int reduce, void *stream)
 {
     SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
-    SKM_REQUIRE(ctx && D > 0 && nchunks >= 0 && chunk_len > 0 && win >= 3 && (win & 1) && Y && out && Y != out && coff && seg_off &&
+    SKM_REQUIRE(ctx && D > 0 && nchunks >= 0 && chunk_len > 0 && win >= 3 && (win & 1) && Y && out && (const void *)Y != out && (out_f64 || compact) && coff && seg_off &&
                     (nchunks == 0 || (chunk_sess && chunk_p0)),
                 "skm_feat_sliding_norm: bad argument");
     if (nchunks == 0) return SKM_OK;
     SkmProfScope ps(ctx, "k_feat_sliding", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_feat_sliding, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Y, Yn, out,
-                       D, idx, coff, seg_off, chunk_sess, chunk_p0, nchunks, chunk_len, win, reduce);
+    const dim3 grid((unsigned)((nchunks + 3) / 4));
+    if (out_f64)
+        hipLaunchKernelGGL(k_feat_sliding<double>, grid, dim3(256), 0, (hipStream_t)stream, Y, Yn, (double *)out, compact,
+                           D, idx, coff, seg_off, chunk_sess, chunk_p0, nchunks, chunk_len, win, reduce);
+    else
+        hipLaunchKernelGGL(k_feat_sliding<float>, grid, dim3(256), 0, (hipStream_t)stream, Y, Yn, (float *)out, compact,
+                           D, idx, coff, seg_off, chunk_sess, chunk_p0, nchunks, chunk_len, win, reduce);
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }

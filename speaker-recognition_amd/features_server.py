@@ -125,12 +125,12 @@ class FeaturesServer(object):
         common = dict(label=label, cols=self.mask, rasta=self.rasta, ndelta=ndelta, delta_filter=self.delta_filter,
                       keep_all=True, out_dtype=torch.float64)
         Y, lab_out, _ = eng.feat_postproc(X, seg, norm=0, **common)
-        # the whole-session pass is only run when some session has at most `win` labelled frames
+        # the whole-session pass is only run when some session has at most `win` labelled frames; without
+        # keep_all the kernel writes the labelled frames only, compacted, in the output type
         out, idx_dev, coff = eng.feat_sliding_norm(
             Y, lambda: eng.feat_postproc(X, seg, norm=2 if reduce else 1, **common)[0], lab_out, seg, win=win,
-            reduce=reduce)
+            reduce=reduce, compact=not keep_all, out_dtype=out_dtype or torch.float32)
         if not keep_all:
-            out = eng.rows_center(out, src=idx_dev)                  # the labelled frames, compacted
             lab_out = torch.ones(out.shape[0], dtype=torch.uint8, device=eng.device)
             out_off = torch.from_numpy(coff).to(eng.device)
         else:

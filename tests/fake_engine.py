@@ -72,7 +72,7 @@ class OracleEngine(object):
         out = torch.from_numpy(np.vstack(feats)).to(out_dtype or torch.float32)
         return out, torch.from_numpy(np.concatenate(labs).astype(np.uint8)), torch.from_numpy(np.array(rows))
 
-    def feat_sliding_norm(self, Y, Yn, label, seg_host, win=301, reduce=False):
+    def feat_sliding_norm(self, Y, Yn, label, seg_host, win=301, reduce=False, compact=False, out_dtype=None):
         """Oracle cep_sliding_norm (sidekit/frontend/normfeat.py:194-229) session by session; same contract as
         HipEngine.feat_sliding_norm (the whole-session fallback is taken from Yn as the device kernel does)."""
         y = Y.numpy().copy()
@@ -88,7 +88,13 @@ class OracleEngine(object):
             else:
                 blk = y[a:b]
                 orc.cep_sliding_norm(blk, lab[a:b], win=win, reduce=reduce)
-        return (torch.from_numpy(y), torch.from_numpy(np.flatnonzero(lab[:seg[-1]]).astype(np.int64)),
+        idx = np.flatnonzero(lab[:seg[-1]]).astype(np.int64)
+        if compact:
+            y = np.ascontiguousarray(y[idx])
+        out = torch.from_numpy(y)
+        if compact:
+            out = out.to(out_dtype or torch.float32)
+        return (out, torch.from_numpy(idx),
                 np.concatenate([[0], np.cumsum(n)]).astype(np.int64))
 
     def moments(self, X):

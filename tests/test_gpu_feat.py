@@ -227,3 +227,12 @@ def test_sliding_normalisation_batch_vs_oracle(sk, keep_all, norm):
         assert off[k + 1] - off[k] == want[k].shape[0], k
         assert np.array_equal(labels[off[k]:off[k + 1]], want_lab[k])
         check(X[off[k]:off[k + 1]], want[k].astype(np.float32), 2e-6)
+
+
+def test_sliding_normalisation_without_any_labelled_frame(sk):
+    """keep_all_features=False and no speech at all: an empty result, no launch on a NULL buffer."""
+    fs = server(sk, dict(mask=None, rasta=False, delta=False, double_delta=False, feat_norm="cmvn_sliding",
+                         keep_all_features=False))
+    x = np.random.RandomState(1).randn(400, 3)
+    f, l = fs.post_processing(x, np.zeros(400, dtype=bool))
+    assert f.shape == (0, 3) and l.shape == (0,)
