@@ -249,7 +249,8 @@ int skm_feat_postproc(void *ctx, const void *X_dev, int in_f64, long ldx, const 
 /* Sliding-window normalisation 'cms_sliding' / 'cmvn_sliding' (sidekit/features_server.py:282-287 ->
  * cep_sliding_norm, sidekit/frontend/normfeat.py:194-229) of a batch of sessions, after skm_feat_postproc with
  * norm = 0 and keep_all = 1:
- *   Y_dev      [rows][D] float64, the un-normalised frames
+ *   Y_dev      [rows][D] float64 (in_f64 = 1) or float32, the un-normalised frames (Yn_dev: same type); the window
+ *              sums are float64 either way; a float32 input needs a float32 output
  *   compact=0: out_dev is another [rows][D] float64 buffer (out_f64 = 1) that starts as a copy of Y
  *   compact=1: out_dev is [labelled frames][D], float32 or float64: frame selection (features_server.py:241-244)
  *              fused in, row of labelled frame p of session s = coff[s] + p; chunk entries of a short session then
@@ -262,7 +263,8 @@ int skm_feat_postproc(void *ctx, const void *X_dev, int in_f64, long ldx, const 
  *   cmvn result of skm_feat_postproc (normfeat.py:206-210); Yn_dev may be NULL when no such session exists
  *   chunk_sess_dev / chunk_p0_dev [nchunks] int32: work list, chunk_len positions per entry -- labelled positions of a
  *   long session, frames of a short one.  win odd (301 in the reference), reduce = 1 for 'cmvn_sliding'. */
-int skm_feat_sliding_norm(void *ctx, const double *Y_dev, const double *Yn_dev, void *out_dev, int out_f64, int compact, int D,
+int skm_feat_sliding_norm(void *ctx, const void *Y_dev, const void *Yn_dev, int in_f64, void *out_dev, int out_f64,
+                          int compact, int D,
                           const int64_t *idx_dev, const int64_t *coff_dev, const int64_t *seg_off_dev,
                           const int *chunk_sess_dev, const int *chunk_p0_dev, int nchunks, int chunk_len, int win,
                           int reduce, void *stream);

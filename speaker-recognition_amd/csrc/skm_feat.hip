@@ -582,8 +582,8 @@ extern "C" int skm_feat_postproc(void *ctx_, const void *X_dev, int in_f64, long
 // buffer: windows reach into neighbouring chunks).  idx: row of every labelled frame, coff: labelled frames before
 // each session.  Float64, no atomics.
 // ------------------------------------------------------------------------------------------------
-template <typename TO>
-__global__ __launch_bounds__(256) void k_feat_sliding(const double *__restrict__ Y, const double *__restrict__ Yn,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void k_feat_sliding(const TI *__restrict__ Y, const TI *__restrict__ Yn,
                                                       TO *__restrict__ out, int compact, int D,
                                                       const int64_t *__restrict__ idx,
                                                       const int64_t *__restrict__ coff, const int64_t *__restrict__ seg,
@@ -616,24 +616,24 @@ __global__ __launch_bounds__(256) void k_feat_sliding(const double *__restrict__
     const double w = (double)win;
     for (int j = lane; j < D; j += 64) {
         long c = p0 < dw ? dw : (p0 > n - dw - 1 ? n - dw - 1 : p0);
-        const double pivot = Y[ix[c - dw] * D + j];
+        const double pivot = (double)Y[ix[c - dw] * D + j];
         double sum = 0.0, ssq = 0.0;
         for (long q = c - dw; q <= c + dw; ++q) {
-            const double v = Y[ix[q] * D + j] - pivot;
+            const double v = (double)Y[ix[q] * D + j] - pivot;
             sum += v;
             ssq += v * v;
         }
         for (long p = p0; p < p1; ++p) {
             const long cn = p < dw ? dw : (p > n - dw - 1 ? n - dw - 1 : p);
             if (cn != c) {      // the window moves by one labelled frame
-                const double vin = Y[ix[cn + dw] * D + j] - pivot;
-                const double vout = Y[ix[c - dw] * D + j] - pivot;
+                const double vin = (double)Y[ix[cn + dw] * D + j] - pivot;
+                const double vout = (double)Y[ix[c - dw] * D + j] - pivot;
                 sum += vin - vout;
                 ssq += vin * vin - vout * vout;
                 c = cn;
             }
             const long r = ix[p];
-            double v = Y[r * D + j] - (pivot + sum / w);
+            double v = (double)Y[r * D + j] - (pivot + sum / w);
             if (reduce) {
                 double var = (ssq - sum * sum / w) / (w - 1.0);
                 if (var < 0.0) var = 0.0;
@@ -644,24 +644,30 @@ __global__ __launch_bounds__(256) void k_feat_sliding(const double *__restrict__
     }
 }
 
-extern "C" int skm_feat_sliding_norm(void *ctx_, const double *Y, const double *Yn, void *out, int out_f64, int compact, int D,
+extern "C" int skm_feat_sliding_norm(void *ctx_, const void *Y, const void *Yn, int in_f64, void *out, int out_f64,
+                                     int compact, int D,
                                      const int64_t *idx, const int64_t *coff, const int64_t *seg_off,
                                      const int *chunk_sess, const int *chunk_p0, int nchunks, int chunk_len, int win,
                                      int reduce, void *stream)
 {
     SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
-    SKM_REQUIRE(ctx && D > 0 && nchunks >= 0 && chunk_len > 0 && win >= 3 && (win & 1) && Y && out && (const void *)Y != out && (out_f64 || compact) && coff && seg_off &&
+    SKM_REQUIRE(ctx && D > 0 && nchunks >= 0 && chunk_len > 0 && win >= 3 && (win & 1) && Y && out && Y != out && (out_f64 || compact) && (in_f64 || !out_f64) && coff && seg_off &&
                     (nchunks == 0 || (chunk_sess && chunk_p0)),
                 "skm_feat_sliding_norm: bad argument");
     if (nchunks == 0) return SKM_OK;
     SkmProfScope ps(ctx, "k_feat_sliding", (hipStream_t)stream);
     const dim3 grid((unsigned)((nchunks + 3) / 4));
-    if (out_f64)
-        hipLaunchKernelGGL(k_feat_sliding<double>, grid, dim3(256), 0, (hipStream_t)stream, Y, Yn, (double *)out, compact,
-                           D, idx, coff, seg_off, chunk_sess, chunk_p0, nchunks, chunk_len, win, reduce);
+#define SKM_SLIDE(TI_, TO_)                                                                                         \
+    hipLaunchKernelGGL((k_feat_sliding<TI_, TO_>), grid, dim3(256), 0, (hipStream_t)stream, (const TI_ *)Y,            \
+                       (const TI_ *)Yn, (TO_ *)out, compact, D, idx, coff, seg_off, chunk_sess, chunk_p0, nchunks,      \
+                       chunk_len, win, reduce)
+    if (in_f64 && out_f64)
+        SKM_SLIDE(double, double);
+    else if (in_f64)
+        SKM_SLIDE(double, float);
     else
-        hipLaunchKernelGGL(k_feat_sliding<float>, grid, dim3(256), 0, (hipStream_t)stream, Y, Yn, (float *)out, compact,
-                           D, idx, coff, seg_off, chunk_sess, chunk_p0, nchunks, chunk_len, win, reduce);
+        SKM_SLIDE(float, float);
+#undef SKM_SLIDE
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }

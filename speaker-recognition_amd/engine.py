@@ -66,7 +66,7 @@ SIGNATURES = {
     "skm_moments_workspace_bytes": (_c_size_t, [_c_void_p, _c_int]),
     "skm_moments": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "skm_feat_workspace_bytes": (_c_size_t, [_c_long, _c_int, _c_int, _c_int]),
-    "skm_feat_sliding_norm": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
+    "skm_feat_sliding_norm": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
                                        _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "skm_feat_postproc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_long, _c_void_p, _c_int, _c_void_p, _c_void_p,
                                    _c_int, _c_long, _c_int, _c_int, _dp, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p,
@@ -416,7 +416,8 @@ class HipEngine(object):
         return C
 
     def feat_sliding_norm(self, Y, Yn, label, seg_host, win=301, reduce=False, compact=False, out_dtype=None):
-        """cep_sliding_norm over a batch (skm_feat_sliding_norm).  Y: un-normalised float64 frames of all sessions,
+        """cep_sliding_norm over a batch (skm_feat_sliding_norm).  Y: un-normalised frames of all sessions (float64, or float32
+        for a float32 result: half the bytes of the window walks),
         Yn: whole-session cms / cmvn of the same frames, or a callable that returns it (called only when a session
         has at most `win` labelled frames), or None; label: uint8 / bool per row (device tensor or host array), seg_host: int64[S+1].
         The index bookkeeping (rows of the labelled frames, labelled frames before each session) stays on the
@@ -424,7 +425,7 @@ class HipEngine(object):
         compact=True writes only the labelled frames (row coff[s] + p), in `out_dtype` (float32 default).
         Returns (out, idx device int64 rows of the labelled frames, coff int64[S+1] host)."""
         torch = self.torch
-        assert Y.dim() == 2 and Y.dtype == torch.float64 and Y.is_contiguous()
+        assert Y.dim() == 2 and Y.dtype in (torch.float32, torch.float64) and Y.is_contiguous()
         seg = np.asarray(seg_host, dtype=np.int64)
         if not isinstance(label, torch.Tensor):
             label = torch.from_numpy(np.ascontiguousarray(np.asarray(label, dtype=np.uint8)))
@@ -439,6 +440,7 @@ class HipEngine(object):
         if callable(Yn):
             Yn = Yn() if short.any() else None
         assert Yn is not None or not short.any()
+        assert Yn is None or (Yn.dtype == Y.dtype and Yn.shape == Y.shape and Yn.is_contiguous())
         span = n if compact else np.where(short, np.diff(seg), n)   # positions to walk per session
         chunk_len = 512             # (win + 2 chunk_len) / chunk_len reads per output: 2.6 (4.4 at 128; 5.2 -> 4.1 ms)
         per = (span + chunk_len - 1) // chunk_len
@@ -447,13 +449,15 @@ class HipEngine(object):
         chunk_p0 = ((np.arange(chunk_sess.size, dtype=np.int64) - np.repeat(first, per)) * chunk_len).astype(np.int32)
         if compact:
             out = torch.empty((int(coff[-1]), Y.shape[1]), dtype=out_dtype or torch.float32, device=self.device)
+            assert Y.dtype == torch.float64 or out.dtype == torch.float32
         else:
             out = Y.clone()
         idx_dev, coff_dev, seg_dev = idx.contiguous(), self._i64_dev(coff), self._i64_dev(seg)
         cs = torch.from_numpy(chunk_sess).to(self.device)
         cp = torch.from_numpy(chunk_p0).to(self.device)
         if chunk_sess.size:
-            self._check(self.lib.skm_feat_sliding_norm(self.ctx, self._ptr(Y), self._ptr(Yn), self._ptr(out),
+            self._check(self.lib.skm_feat_sliding_norm(self.ctx, self._ptr(Y), self._ptr(Yn),
+                                                       1 if Y.dtype == torch.float64 else 0, self._ptr(out),
                                                        1 if out.dtype == torch.float64 else 0, 1 if compact else 0, Y.shape[1],
                                                        self._ptr(idx_dev), self._ptr(coff_dev), self._ptr(seg_dev),
                                                        self._ptr(cs), self._ptr(cp), int(chunk_sess.size), chunk_len, int(win),

@@ -122,8 +122,11 @@ class FeaturesServer(object):
         eng = self.engine
         torch = eng.torch
         reduce = self.feat_norm == 'cmvn_sliding'
+        # the un-normalised frames are float64 unless the result is float32 and compacted (the statistics kernels'
+        # input): then float32 halves the bytes of the window walks, whose sums stay float64
+        mid = torch.float32 if (not keep_all and (out_dtype or torch.float32) == torch.float32) else torch.float64
         common = dict(label=label, cols=self.mask, rasta=self.rasta, ndelta=ndelta, delta_filter=self.delta_filter,
-                      keep_all=True, out_dtype=torch.float64)
+                      keep_all=True, out_dtype=mid)
         Y, lab_out, _ = eng.feat_postproc(X, seg, norm=0, **common)
         # the whole-session pass is only run when some session has at most `win` labelled frames; without
         # keep_all the kernel writes the labelled frames only, compacted, in the output type
