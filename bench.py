@@ -11,15 +11,23 @@ buffer when N > 1, the float64 M-step and the re-pack of the model -- i.e. the b
 EM_split loop (reference mixture.py:686-710).  Weak scaling: every rank holds its own 10 M frames.
 `value` = frames processed by all ranks / max-over-ranks time.
 
-Also reported on the same JSON line (rank 0, N=1 detail):
-  roofline      dominant kernel (k_stats_em) against the f32 MFMA peak, timed with HIP events on
-                the launch stream inside the library (skm_prof_*), algorithmic flops only
+`--gpus N` with N > 1 and no torchrun environment: this process touches no GPU, starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py` as a CHILD (fresh processes, one per GPU)
+and relays rank 0's JSON line.  Under torchrun (WORLD_SIZE set) it is one of the ranks.
+
+Also reported on the same JSON line (rank 0):
+  roofline      dominant kernel against the f32 MFMA peak, timed with HIP events on the launch stream
+                inside the library (skm_prof_*), algorithmic flops only
   roofline_path the whole E-step (8*D*C flop/frame) over the sum of its kernels
   cpu_baseline  the NumPy float64 oracle (a port of the reference's call sequence) on a bounded
-                sample of the same workload, host cores stated
-  bw_stats      Baum-Welch N/F accumulation (configs[3] at reduced session count), frames/s
-  tv            TV training iteration and i-vector extraction (configs[4] at reduced session count)
-  feat          feature post-processing in front of the path (RASTA, deltas, cmvn, VAD selection), HBM roofline
+                sample of the same workload, host cores stated (N=1 only)
+  em_split      BASELINE configs[1] whole: Mixture.EM_split to 512 components, 37 EM iterations over 9 splits
+  em_c2048      BASELINE configs[2] per-GPU shard: EM iteration at C=2048 on 12.5 M frames per GPU (weak scaling)
+  bw_stats      BASELINE configs[3]: Baum-Welch N/F, C=2048, 50 000 sessions x 2 000 frames in total, sessions
+                split over the ranks (strong scaling); `api` = host arrays in -> host arrays out on a bounded sample
+  tv            BASELINE configs[4]: TV training iteration + extract_ivectors, R=400, C=2048, 50 000 sessions in
+                total, split over the ranks (strong scaling); `api` as above
+  scoring, feat the "next" rows either side of the path
 """
 import argparse
 import json
@@ -34,6 +42,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F64_MFMA_TFLOPS = 78.6    # MI355X_MICROARCH.md, "Peak FP64 (matrix)"
 PEAK_HBM_GBS = 8000.0
 
 
@@ -147,27 +156,85 @@ def cpu_baseline_tv(C, D, R, seconds_target=10.0):
             "sample": "oracle (NumPy/SciPy f64) e_on_batch, C=%d D=%d R=%d, %d sessions, %.1f s" % (C, D, R, n, dt)}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """Start n fresh rank processes (one per GPU) through torch.distributed.run and relay rank 0's JSON line.
+    The calling process has not touched the GPU (nothing is re-executed after a HIP call); it only waits."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line)
+    return rc if rc != 0 or line is not None else 1
+
+
+def launch_check(world, rank, local_rank):
+    """--launch-check: what the launcher handed to this rank, collected over gloo (no GPU is touched)."""
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    got = [None] * world
+    td.all_gather_object(got, {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid()})
+    if rank == 0:
+        print(json.dumps({"metric": "launch-check", "n_gpus": world, "ranks": got}))
+    td.barrier()
+    td.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=10_000_000, help="frames per GPU")
+    ap.add_argument("--frames", type=int, default=10_000_000, help="frames per GPU of the headline workload")
     ap.add_argument("--comps", type=int, default=512)
     ap.add_argument("--dim", type=int, default=60)
-    ap.add_argument("--tv-sessions", type=int, default=8192)
+    ap.add_argument("--em2048-frames", type=int, default=12_500_000, help="frames per GPU of the em_c2048 leg")
+    ap.add_argument("--bw-sessions", type=int, default=50_000, help="sessions of the bw_stats leg, all ranks together")
+    ap.add_argument("--tv-sessions", type=int, default=50_000, help="sessions of the tv leg, all ranks together")
     ap.add_argument("--tv-batch", type=int, default=4096, help="sessions per TV E-step batch")
+    ap.add_argument("--api-sessions", type=int, default=4000, help="sessions of the host-in / host-out samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (BW stats)")
-    ap.add_argument("--legs", default="bw,em2048,scoring,feat,tv",
-                    help="secondary legs (comma list of bw, em2048, scoring, feat, tv)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs")
+    ap.add_argument("--legs", default="em_split,em2048,bw,scoring,feat,tv",
+                    help="secondary legs (comma list of em_split, em2048, bw, scoring, feat, tv)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only report the rank layout the launcher produced (gloo, no GPU); used by the CPU tests")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as td
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        launch_check(world, rank, local_rank)
+        return
+
+    import torch
+    import torch.distributed as td
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -181,8 +248,11 @@ def main():
     eng = sk.default_engine()
     C, D, T = args.comps, args.dim, args.frames
     legs = set() if args.no_extra else set(x for x in args.legs.split(",") if x)
+    api_stats = None
 
-    X = synth_frames_device(torch, T, D, seed=1234 + rank, device=dev)
+    T_all = max(T, args.em2048_frames if "em2048" in legs else 0)
+    X_all = synth_frames_device(torch, T_all, D, seed=1234 + rank, device=dev)
+    X = X_all[:T]
     ubm = random_ubm(sk, C, D)
 
     def sync():
@@ -251,14 +321,16 @@ def main():
                               "algorithmic_flop_per_launch": flop_dom}
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same workload (a process
         # cannot read its own PMC counters); the committed summary is used only when the workload matches
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_hbm_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             if pmc["workload"] == {"C": C, "D": D, "frames": T}:
                 for name, rec in pmc["kernels"].items():
                     if name.startswith(dom):
                         result["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
-                        result["roofline"]["traffic_source"] = "profiles/r1_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE)"
+                        result["roofline"]["traffic_source"] = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE)" % os.path.basename(pmc_path)
                         result["roofline"]["algorithmic_bytes_per_launch"] = 4.0 * D * T
                         if "mfma_util" in rec:
                             result["roofline"]["mfma_util_pmc"] = rec["mfma_util"]
@@ -270,27 +342,56 @@ def main():
 
     # The secondary legs run on EVERY rank (weak scaling: each rank owns its sessions / frames); values are
     # whole-job aggregates over the MAX-over-ranks wall time, kernel tables are rank 0's.
+    def shard(n):
+        """this rank's share of n units that the whole job splits (strong-scaling legs)"""
+        lo, hi = sk.dist.shard_bounds(n, world, rank)
+        return hi - lo
+
+    if "em_split" in legs:
+        # ---- BASELINE configs[1] whole: Mixture.EM_split to C components on the rank's frames, the reference's
+        # default schedule (37 EM iterations over 9 binary splits at C = 512); frames sharded, statistics all-reduced
+        fs_all = sk.FeaturesServer(features={"all": X}, is_sharded=True)
+        sk.Mixture().EM_split(sk.FeaturesServer(features={"w": X[:200000]}, is_sharded=True), ["w"], distrib_nb=C)
+        ubm_s = sk.Mixture()
+        eng.profile(True)
+        dts, llk_s = timed(lambda: ubm_s.EM_split(fs_all, ["all"], distrib_nb=C), 1)
+        prof = eng.profile_read()
+        eng.profile(False)
+        sched = (1, 2, 2, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8)[:int(np.log2(C))]
+        flop = 8.0 * D * T * sum(it * (2 << i) for i, it in enumerate(sched))
+        result["em_split"] = {"value": world * T * sum(sched) / dts, "unit": "frame-iterations/s", "n_gpus": world,
+                              "seconds": dts, "em_iterations": len(llk_s),
+                              "workload": "Mixture.EM_split, %d frames per GPU x %d dims -> %d components, schedule %s "
+                                          "(BASELINE configs[1])" % (T, D, C, list(sched)),
+                              "final_mean_llk": float(llk_s[-1]),
+                              "kernels_ms": {k: round(v[1], 2) for k, v in sorted(prof.items())},
+                              "path_frac_of_mfma_peak": flop / dts / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        del fs_all, ubm_s
+
     if "bw" in legs:
-        # ---- Baum-Welch N/F accumulation (BASELINE configs[3], fewer sessions): C=2048, 2000-frame sessions.
-        # No data-path collective: every session row has one owner.
-        Cb, S, L = 2048, min(5000, T // 2000), 2000
+        # ---- Baum-Welch N/F accumulation, BASELINE configs[3]: C=2048, 50 000 sessions x 2 000 frames in the whole
+        # job, the sessions split over the ranks.  No data-path collective: every session row has one owner.
+        Cb, L = 2048, 2000
+        S = shard(args.bw_sessions)
         ubm_b = random_ubm(sk, Cb, D, seed=11)
         packed = eng.pack(ubm_b.w, ubm_b.mu, ubm_b.invcov)
         seg = torch.arange(0, S + 1, dtype=torch.int64, device=dev) * L
-        Xb = X[:S * L]
+        Xb = X_all[:S * L] if S * L <= T_all else synth_frames_device(torch, S * L, D, seed=4321 + rank, device=dev)
         s0 = torch.empty((S, Cb), dtype=torch.float64, device=dev)
         s1 = torch.empty((S, Cb * D), dtype=torch.float64, device=dev)
-        eng.bw_stats(Xb, seg, packed, s0, s1)
+        nw = min(S, 500)
+        eng.bw_stats(Xb[:nw * L], seg[:nw + 1], packed, s0[:nw], s1[:nw])          # warm-up
         eng.profile(True)
-        dtb, _ = timed(lambda: eng.bw_stats(Xb, seg, packed, s0, s1), 2)
-        dtb /= 2
+        dtb, _ = timed(lambda: eng.bw_stats(Xb, seg, packed, s0, s1), 1)
         prof = eng.profile_read()
         eng.profile(False)
         k_bw = "k_bw_team" if "k_bw_team" in prof else "k_stats_bw"
         t_bw = prof[k_bw][1] / prof[k_bw][0]
         fl_bw = (6.0 if k_bw == "k_bw_team" else 2.0) * D * Cb * S * L
-        result["bw_stats"] = {"value": world * S * L / dtb, "unit": "frames/s", "n_gpus": world,
-                              "workload": "accumulate_stat body, C=%d, %d sessions x %d frames per GPU" % (Cb, S, L),
+        result["bw_stats"] = {"value": args.bw_sessions * L / dtb, "unit": "frames/s", "n_gpus": world, "scaling": "strong",
+                              "seconds": dtb,
+                              "workload": "accumulate_stat body, C=%d, %d sessions x %d frames in total (BASELINE configs[3]), "
+                                          "%d sessions on rank 0" % (Cb, args.bw_sessions, L, S),
                               "roofline": {"bound": "mfma", "kernel": k_bw,
                                            "achieved": fl_bw / (t_bw * 1e-3) / 1e12,
                                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -298,12 +399,39 @@ def main():
                                            "avg_launch_ms": t_bw},
                               "path_frac_of_mfma_peak": 6.0 * D * Cb * S * L / dtb / 1e12 / PEAK_F32_MFMA_TFLOPS}
         del s0, s1
+        if Xb.data_ptr() != X_all.data_ptr():
+            del Xb
+        torch.cuda.empty_cache()
+        if rank == 0 and world == 1:
+            # API level (host arrays in -> host arrays out) on a bounded sample: StatServer.accumulate_stat fed by an
+            # in-memory features server; upload of the frames and download of stat0 / stat1 included
+            Sa = min(args.api_sessions, S)
+            host = X_all[:Sa * L].cpu().numpy()
+            names = ["s%05d" % i for i in range(Sa)]
+            fsa = sk.FeaturesServer(features={n: host[i * L:(i + 1) * L] for i, n in enumerate(names)})
+            ssa = sk.StatServer(sk.IdMap().set(names, names), ubm=ubm_b, engine=eng)
+            t0 = time.perf_counter()
+            ssa.accumulate_stat(ubm=ubm_b, feature_server=fsa, seg_indices=range(Sa), gather=False)
+            dta = time.perf_counter() - t0
+            ssb = sk.StatServer(sk.IdMap().set(names, names), ubm=ubm_b, engine=eng)
+            t0 = time.perf_counter()
+            ssb.accumulate_stat(ubm=ubm_b, feature_server=fsa, seg_indices=range(Sa), gather=False, keep_on_device=True)
+            dtk = time.perf_counter() - t0
+            result["bw_stats"]["api"] = {"value": Sa * L / dta, "unit": "frames/s", "seconds": dta,
+                                         "sample": "StatServer.accumulate_stat, %d sessions x %d frames on one GPU: host float32 "
+                                                   "frames in (%.1f GB), host float64 stat0/stat1 out (%.1f GB)"
+                                                   % (Sa, L, host.nbytes / 1e9, (ssa.stat0.nbytes + ssa.stat1.nbytes) / 1e9),
+                                         "seconds_keep_on_device": dtk}
+            api_stats = ssb                    # device-resident rows feed the tv api sample below
+            del host, fsa, ssa
+        if world > 1:
+            td.barrier()
 
     if "em2048" in legs:
         # ---- EM iteration at the target size (BASELINE configs[2] per-GPU shape, fewer frames): C=2048
-        Ce, Te = 2048, min(T, 4_000_000)
+        Ce, Te = 2048, args.em2048_frames
         ubm_e = random_ubm(sk, Ce, D, seed=11)
-        Xe = X[:Te]
+        Xe = X_all[:Te]
         em_iterations(ubm_e, Xe, 1)
         eng.profile(True)
         dte, _ = timed(lambda: em_iterations(ubm_e, Xe, 2), 1)
@@ -314,8 +442,8 @@ def main():
         t_k = sum(kte.values())
         result["em_c2048"] = {"value": world * Te / dte, "unit": "frames/s", "n_gpus": world,
                               "ms_per_iteration": 1e3 * dte,
-                              "workload": "UBM EM iteration (E-step + all-reduce + M-step), C=%d, D=%d, %d frames per GPU"
-                                          % (Ce, D, Te),
+                              "workload": "UBM EM iteration (E-step + all-reduce + M-step), C=%d, D=%d, %d frames per GPU "
+                                          "(BASELINE configs[2]: 100 M frames over 8 GPUs)" % (Ce, D, Te),
                               "kernels_ms": {k: round(v, 3) for k, v in kte.items()},
                               "roofline_path": {"bound": "mfma", "achieved": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12,
                                                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -457,30 +585,36 @@ def main():
         del raw, vad, fo
 
     if "tv" in legs:
-        # ---- TV training iteration + i-vector extraction (BASELINE configs[4], fewer sessions): R=400, C=2048.
-        # Sessions are sharded (each rank owns --tv-sessions of them); training reduce-scatters the accumulators
-        # over components, solves its C/N components and all-gathers the new rows (factor_analyser._tv_iteration).
-        del X
+        # ---- TV training iteration + i-vector extraction, BASELINE configs[4]: R=400, C=2048, 50 000 sessions in the
+        # whole job, split over the ranks; training reduce-scatters the accumulators over components, solves its C/N
+        # components and all-gathers the new rows (factor_analyser._tv_iteration).
+        del X, X_all
         torch.cuda.empty_cache()
-        Ct, R, St = 2048, 400, args.tv_sessions
+        Ct, R = 2048, 400
+        St = shard(args.tv_sessions)
         ubm_t = random_ubm(sk, Ct, D, seed=11)
         gen = torch.Generator(device=dev)
         gen.manual_seed(4321 + rank)
-        post = torch.softmax(2.0 * torch.randn(St, Ct, generator=gen, device=dev), dim=1)
-        stat0 = (2000.0 * post).to(torch.float32)
         mu_sv = torch.as_tensor(ubm_t.get_mean_super_vector(), device=dev)
         sd_sv = torch.as_tensor(1.0 / np.sqrt(ubm_t.get_invcov_super_vector()), device=dev)
-        n_rep = stat0.repeat_interleave(D, dim=1).to(torch.float64)
-        stat1 = (n_rep * mu_sv + torch.sqrt(n_rep) * sd_sv *
-                 torch.randn(St, Ct * D, generator=gen, device=dev, dtype=torch.float64)).to(torch.float32)
-        del n_rep, post
+        stat0 = torch.empty((St, Ct), dtype=torch.float32, device=dev)
+        stat1 = torch.empty((St, Ct * D), dtype=torch.float32, device=dev)
+        for a0 in range(0, St, 2048):                  # synthetic statistics, built in slices (float64 temporaries)
+            b0 = min(St, a0 + 2048)
+            post = torch.softmax(2.0 * torch.randn(b0 - a0, Ct, generator=gen, device=dev), dim=1)
+            stat0[a0:b0] = (2000.0 * post).to(torch.float32)
+            n_rep = stat0[a0:b0].repeat_interleave(D, dim=1).to(torch.float64)
+            stat1[a0:b0] = (n_rep * mu_sv + torch.sqrt(n_rep) * sd_sv *
+                            torch.randn(b0 - a0, Ct * D, generator=gen, device=dev, dtype=torch.float64)).to(torch.float32)
+            del n_rep, post
         ft, naug = eng.tv_whiten(stat0, stat1, ubm_t.get_mean_super_vector(), ubm_t.get_invcov_super_vector())
         del stat1
+        torch.cuda.empty_cache()
         fa = sk.FactorAnalyser()
         tv_state = {"T": torch.as_tensor(0.1 * np.random.RandomState(7).randn(Ct * D, R), device=dev)}
 
         def tv_iter():
-            tv_state["T"] = fa._tv_iteration(ft, naug, tv_state["T"], Ct, D, R, world * St, True, args.tv_batch)
+            tv_state["T"] = fa._tv_iteration(ft, naug, tv_state["T"], Ct, D, R, args.tv_sessions, True, args.tv_batch)
         tv_iter()                                                               # warm-up iteration
         eng.profile(True)
         dt_tv, _ = timed(tv_iter, 1)
@@ -492,19 +626,69 @@ def main():
         eng.profile_read()
         eng.profile(False)
         flop_train, flop_iv = 9.18e8, 4.5e8          # algorithmic flop per session
+        Sall = args.tv_sessions
+        # float64 chain of the E-step (Cholesky, triangular inverse, X X'): algorithmic R^3 flop per session
+        t_f64 = sum(v[1] for k, v in prof_tv.items()
+                    if k in ("k_chol_diag", "k_gemm_chol_panel", "k_gemm_chol_update", "k_gemm_trinv_a", "k_gemm_trinv_b",
+                             "k_gemm_xxt", "k_chol_row", "k_trinv_row"))
         result["tv"] = {
-            "workload": "TV EM iteration (E-step + M-step + min-div) and extract_ivectors, R=%d, C=%d, D=%d, "
-                        "%d synthetic sessions per GPU" % (R, Ct, D, St), "n_gpus": world,
-            "train_sessions_per_s": world * St / dt_tv, "train_s_per_iteration": dt_tv,
-            "train_algorithmic_tflops": flop_train * world * St / dt_tv / 1e12,
-            "ivectors_per_s": world * St / dt_iv,
-            "ivectors_with_uncertainty_per_s": world * St / dt_ivu,
-            "extract_algorithmic_tflops": flop_iv * world * St / dt_iv / 1e12,
+            "workload": "TV EM iteration (E-step + M-step + min-div) and extract_ivectors, R=%d, C=%d, D=%d, %d synthetic "
+                        "sessions in total (BASELINE configs[4]), %d on rank 0" % (R, Ct, D, Sall, St),
+            "n_gpus": world, "scaling": "strong",
+            "train_sessions_per_s": Sall / dt_tv, "train_s_per_iteration": dt_tv,
+            "train_algorithmic_tflops": flop_train * Sall / dt_tv / 1e12,
+            "train_frac_of_f32_mfma_peak": flop_train * Sall / dt_tv / 1e12 / PEAK_F32_MFMA_TFLOPS / world,
+            "ivectors_per_s": Sall / dt_iv,
+            "ivectors_with_uncertainty_per_s": Sall / dt_ivu,
+            "extract_algorithmic_tflops": flop_iv * Sall / dt_iv / 1e12,
+            "extract_frac_of_f32_mfma_peak": flop_iv * Sall / dt_iv / 1e12 / PEAK_F32_MFMA_TFLOPS / world,
+            "f64_chain": {"ms": round(t_f64, 3), "algorithmic_tflops": float(R) ** 3 * St / (t_f64 * 1e-3) / 1e12 if t_f64 else None,
+                          "frac_of_f64_mfma_peak": float(R) ** 3 * St / (t_f64 * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS if t_f64 else None},
             "train_kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof_tv.items())},
             "extract_kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof_iv.items())},
-            "note": "M-step cost (R x R inverses of the rank's C/N components) is independent of the session count "
-                    "and is amortised over 50k sessions in configs[4]; it is included in train_s_per_iteration here"}
-        del ft, naug, T32, G
+            "note": "M-step cost (R x R inverses of the rank's C/N components) is independent of the session count; it is "
+                    "included in train_s_per_iteration"}
+        del ft, naug, T32, G, stat0
+        torch.cuda.empty_cache()
+        if rank == 0 and world == 1:
+            # API level on a bounded sample: FactorAnalyser.total_variability (one iteration) and extract_ivectors on
+            # an in-memory StatServer -- host statistics in, host F / i-vectors out -- and the same calls on a
+            # StatServer whose rows accumulate_stat left in HBM (keep_on_device=True): no upload of the statistics
+            Sa = min(args.api_sessions, St)
+            rs = np.random.RandomState(5)
+            ssh = sk.StatServer(engine=eng)
+            ssh.modelset = np.array(["m%05d" % i for i in range(Sa)])
+            ssh.segset = ssh.modelset.copy()
+            ssh.start = np.empty(Sa, "|O")
+            ssh.stop = np.empty(Sa, "|O")
+            if api_stats is not None and api_stats.stat0.shape[0] >= Sa:
+                ssh.stat0, ssh.stat1 = api_stats.stat0[:Sa], api_stats.stat1[:Sa]
+            else:
+                ssh.stat0 = 2000.0 * rs.dirichlet(np.full(Ct, 0.3), size=Sa)
+                ssh.stat1 = np.repeat(ssh.stat0, D, axis=1) * ubm_t.get_mean_super_vector() + rs.randn(Sa, Ct * D)
+            tv0 = 0.1 * np.random.RandomState(7).randn(Ct * D, R)
+            fa_api = sk.FactorAnalyser(engine=eng)
+            t0 = time.perf_counter()
+            fa_api.total_variability_single(ssh, ubm_t, R, nb_iter=1, min_div=True, tv_init=tv0)
+            dt_a = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            ivs = fa_api.extract_ivectors(ubm_t, ssh)
+            dt_e = time.perf_counter() - t0
+            api = {"sample": "%d sessions on one GPU, host float64 statistics in (%.1f GB), host F / i-vectors out; the "
+                             "M-step of all %d components is included in the training figure" % (Sa, (ssh.stat0.nbytes + ssh.stat1.nbytes) / 1e9, Ct),
+                   "train_sessions_per_s": Sa / dt_a, "train_seconds": dt_a,
+                   "ivectors_per_s": Sa / dt_e, "extract_seconds": dt_e,
+                   "iv_finite": bool(np.isfinite(ivs.stat1).all())}
+            if api_stats is not None and api_stats.resident_rows() is not None and api_stats.stat0.shape[0] == Sa:
+                t0 = time.perf_counter()
+                fa_api.total_variability_single(api_stats, ubm_t, R, nb_iter=1, min_div=True, tv_init=tv0)
+                api["train_seconds_resident"] = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                fa_api.extract_ivectors(ubm_t, api_stats)
+                api["extract_seconds_resident"] = time.perf_counter() - t0
+            result["tv"]["api"] = api
+        if world > 1:
+            td.barrier()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(C, D)

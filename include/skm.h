@@ -89,6 +89,21 @@ size_t skm_gmm_workspace_bytes(void *ctx, long T, int C, int D);
 int skm_gmm_estep(void *ctx, const float *X_dev, long T, int C, int D, const void *packed_dev,
                   double *out_dev, int accumulate, void *ws_dev, size_t ws_bytes, void *stream);
 
+/* skm_gmm_estep for callers that cannot allocate or size a workspace: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Same arguments and results
+ * as skm_gmm_estep minus the workspace: the kernels' scratch (per-wave float64 slabs, log-likelihood partials,
+ * team hand-off rows) is a file-scope device array of skm_gmm_estep_noalloc_max_bytes() = 144 MiB that every GPU
+ * the library runs on holds until the process ends.  The call allocates nothing (no hipMalloc / hipFree; keep
+ * skm_prof_enable off, its events are created per launch).
+ *   - shapes with a single-sweep kernel (C in {256, 512, 1024, 2048, 4096}, D % 4 == 0, D <= 64): any T;
+ *   - other shapes take two sweeps whose per-frame partials live in the scratch too: T is bounded, and a call
+ *     that does not fit returns SKM_ERR_WORKSPACE with the sizes in skm_last_error();
+ *   - all calls on one GPU share that GPU's array: what must start at zero is cleared on `stream` by every
+ *     call, and calls that overlap in time on one GPU (two streams, two threads) race. */
+size_t skm_gmm_estep_noalloc_max_bytes(void);
+int skm_gmm_estep_noalloc(void *ctx, const float *X_dev, long T, int C, int D, const void *packed_dev,
+                          double *out_dev, int accumulate, void *stream);
+
 /* Per-frame log-likelihood log sum_c w_c N(x_t; mu_c, Sigma_c) (natural log, float32, dev).
  * Replaces compute_log_posterior_probabilities + the log_lk of sum_log_probabilities
  * (sidekit/statserver.py:83-95; used by gmm_scoring, sidekit/gmm_scoring.py:102-111). */

@@ -200,14 +200,16 @@ def init_uniform(cep, distrib_nb):
 
 
 def em_split(chunks, distrib_nb, iterations=(1, 2, 2, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8),
-             ceil_cov=10, floor_cov=1e-2, trace=None):
+             ceil_cov=10, floor_cov=1e-2, trace=None, init_chunks=None):
     """Binary-split EM (sidekit/mixture.py:643-733), num_thread=1 semantics.
 
-    `chunks` is the list of per-file frame blocks the features server would return.
-    Returns (gmm, llk list).  `trace`, if a list, receives a copy of the model after
-    every M-step.
+    `chunks` is the list of per-file frame blocks the features server returns to the E-steps, i.e.
+    with keep_all_features = False (sidekit/mixture.py:585); `init_chunks` the blocks _init stacks
+    with the server's own setting (sidekit/mixture.py:629) when that differs (VAD labels present and
+    keep_all_features = True).  Returns (gmm, llk list).  `trace`, if a list, receives a copy of the
+    model after every M-step.
     """
-    gmm = init_single(np.vstack(chunks))
+    gmm = init_single(np.vstack(chunks if init_chunks is None else init_chunks))
     llk = []
     for it in iterations[:int(np.log2(distrib_nb))]:
         split(gmm)

@@ -27,6 +27,9 @@ struct SkmCtx {
     int cu_count;
     int prof_on;
     std::vector<SkmProfRec> prof;
+    // address, on this ctx's GPU, of the file-scope scratch array of skm_gmm.hip (skm_gmm_estep_noalloc);
+    // looked up once in skm_ctx_create with the device current
+    void *scratch;
 };
 
 struct SkmProfScope {

@@ -39,7 +39,15 @@ void skm_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *skm_last_error(void) { return g_err; }
-extern "C" int skm_version(void) { return 100; }
+extern "C" int skm_version(void) { return 101; }
+
+// Scratch of skm_gmm_estep_noalloc: the E-step workspace of the single-sweep kernels (per-wave float64 slabs,
+// log-likelihood partials, team hand-off rows and flags) as a file-scope device array, so that the entry point
+// needs no workspace argument and allocates nothing.  Every GPU the library runs on holds its own copy until the
+// process ends.  In host code this NAME is only a handle for hipGetSymbolAddress: the address used everywhere
+// (kernel arguments, hipMemsetAsync) is SkmCtx::scratch, looked up once per device in skm_ctx_create.
+#define SKM_SCRATCH_BYTES ((size_t)144 << 20)
+static __device__ __align__(256) unsigned char scratch[SKM_SCRATCH_BYTES];
 
 extern "C" int skm_ctx_create(int device, void **ctx)
 {
@@ -54,10 +62,23 @@ extern "C" int skm_ctx_create(int device, void **ctx)
                       prop.gcnArchName);
         return SKM_ERR_UNSUPPORTED;
     }
+    // this GPU's copy of the scratch array: its address is per device, so it is taken with `device` current
+    int prev = 0;
+    SKM_HIP(hipGetDevice(&prev));
+    SKM_HIP(hipSetDevice(device));
+    void *sp = nullptr;
+    const hipError_t se = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+    (void)hipSetDevice(prev);
+    if (se != hipSuccess || sp == nullptr) {
+        skm_set_error("skm_ctx_create: hipGetSymbolAddress(scratch) failed on device %d: %s", device,
+                      hipGetErrorString(se));
+        return SKM_ERR_HIP;
+    }
     SkmCtx *c = new SkmCtx();
     c->device = device;
     c->cu_count = prop.multiProcessorCount;
     c->prof_on = 0;
+    c->scratch = sp;
     *ctx = c;
     return SKM_OK;
 }
@@ -661,7 +682,7 @@ __device__ __forceinline__ void flush_slab(f32x16 (&acc)[NCT][NF], double *slab_
 // column) to stat0.
 template <int NCT, int NF>
 __device__ __forceinline__ void flush_session(f32x16 (&acc)[NCT][NF], double *s0, double *s1, int cb, int C,
-                                              int D, int lane)
+                                              int D, int lane, bool add = false)
 {
     const int h = lane >> 5, c = lane & 31;
 #pragma unroll
@@ -675,7 +696,10 @@ __device__ __forceinline__ void flush_session(f32x16 (&acc)[NCT][NF], double *s0
             const int nlive = (col <= D) ? (C - comp0) : 0;  // rows acc_row(r,0) < nlive are stored
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (acc_row(r, 0) < nlive) p[acc_row(r, 0) * stride] = (double)acc[ct][jf][r];
+                if (acc_row(r, 0) < nlive) {
+                    double *q = p + acc_row(r, 0) * stride;
+                    *q = add ? (*q + (double)acc[ct][jf][r]) : (double)acc[ct][jf][r];
+                }
                 acc[ct][jf][r] = 0.f;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -739,17 +763,23 @@ __global__ __launch_bounds__(512, 2) void k_stats(StatsArgs a)
         }
     } else {
         // Baum-Welch: sessions are dealt round-robin to the wave slots of this component block;
-        // one session = one f32 accumulation, stored as f64 at its end.
+        // the f32 accumulators of a session are folded into its float64 output rows every SKM_FLUSH_TILES
+        // tiles (first fold stores, later ones add: one owner per entry), as the EM slabs are.
         const int C = a.C, D = g.D;
 #pragma unroll 1
         for (long s = slot; s < a.S; s += n_slots) {
             const long b = a.seg_off[s], e = a.seg_off[s + 1];
+            long pb = b;
+            do {
+                const long pe = (pb + 32L * SKM_FLUSH_TILES < e) ? pb + 32L * SKM_FLUSH_TILES : e;
 #pragma unroll 1
-            for (long t0 = b; t0 < e; t0 += 32) {
-                const int nvalid = (int)((e - t0) < 32 ? (e - t0) : 32);
-                stats_tile<NJT, NCT, WITH_S>(acc, xs, ls, a.X, a.lse2, t0, nvalid, g, Wl4, kcv, lane);
-            }
-            flush_session<NCT, NF>(acc, a.stat0 + s * (long)C, a.stat1 + s * (long)C * D, cb, C, D, lane);
+                for (long t0 = pb; t0 < pe; t0 += 32) {
+                    const int nvalid = (int)((pe - t0) < 32 ? (pe - t0) : 32);
+                    stats_tile<NJT, NCT, WITH_S>(acc, xs, ls, a.X, a.lse2, t0, nvalid, g, Wl4, kcv, lane);
+                }
+                flush_session<NCT, NF>(acc, a.stat0 + s * (long)C, a.stat1 + s * (long)C * D, cb, C, D, lane, pb > b);
+                pb = pe;
+            } while (pb < e);
         }
     }
 }
@@ -1572,7 +1602,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
 // NCT * 32 for every caller, so every accumulator row is a live component.
 template <int NCT, int NF>
 __device__ __forceinline__ void flush_session_agpr(f32x16 (&acc)[NCT][NF], double *s0, double *s1, int cb, int D,
-                                                   int lane)
+                                                   int lane, bool add = false)
 {
     const int h = lane >> 5, c = lane & 31;
 #pragma unroll
@@ -1586,8 +1616,16 @@ __device__ __forceinline__ void flush_session_agpr(f32x16 (&acc)[NCT][NF], doubl
             double *p = (col < D) ? (s1 + (long)comp0 * D + col) : (s0 + comp0);
             const long stride = (col < D) ? D : 1;
             if (col <= D) {
+                if (!add) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) p[acc_row(r, 0) * stride] = (double)v[r];
+                    for (int r = 0; r < 16; ++r) p[acc_row(r, 0) * stride] = (double)v[r];
+                } else {   // later fold of a long session: this lane is the only writer of these entries
+                    double old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[r] = p[acc_row(r, 0) * stride];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p[acc_row(r, 0) * stride] = old[r] + (double)v[r];
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
@@ -1652,6 +1690,7 @@ struct TeamArgs {
     int S, C;
     double *stat0, *stat1;
     int w_bytes;          // size of the packed W image
+    int debug_drop;       // tests only (SKM_DEBUG_TEAM_DROP=1, Baum-Welch mode): contribution 1 never raises its flag
 #ifdef SKM_TRACE
     long long *trace;
 #endif
@@ -2040,9 +2079,10 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
     // gamma and statistics of tile ni (its e values are in lg, its partial rows in part[]); t_pf >= 0 names
     // the frames to request for a later tile (the statistics GEMM has no other vector-memory wait)
     // flag of a published row, as in k_estep_team (flag_val = 0: nothing to publish)
+    const bool muted = BW && a.debug_drop && me == 1;   // wave-uniform, tests only
     auto publish_flag = [&](int flag_slot, unsigned flag_val) __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
+        if (lane == 0 && !muted)
             __hip_atomic_store(flags + flag_slot * NC + me, flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto finish_tile = [&](f32x16 (&lg)[NCT], unsigned ni, int nvalid, long t_pf, int nv_pf, int flag_slot,
@@ -2256,12 +2296,34 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
         };
         const int sa = (team == 0) ? 0 : lower(total * team / n_teams);
         const int sb = (team == n_teams - 1) ? a.S : lower(total * (team + 1) / n_teams);
+        // a session longer than SKM_FLUSH_TILES tiles is run in pieces and its f32 accumulators are folded into
+        // the float64 output rows after each piece (first fold stores, later ones add), like the EM slabs
 #pragma unroll 1
         for (int sidx = sa; sidx < sb; ++sidx) {
-            run_segment(so[sidx], so[sidx + 1]);
-            flush_session_agpr<NCT, NF>(acc, a.stat0 + (long)sidx * a.C, a.stat1 + (long)sidx * a.C * g.D, me, g.D, lane);
+            const long sb0 = so[sidx], se0 = so[sidx + 1];
+            long pb = sb0;
+#pragma unroll 1
+            do {
+                const long pe = (pb + 32L * SKM_FLUSH_TILES < se0) ? pb + 32L * SKM_FLUSH_TILES : se0;
+                run_segment(pb, pe);
+                flush_session_agpr<NCT, NF>(acc, a.stat0 + (long)sidx * a.C, a.stat1 + (long)sidx * a.C * g.D, me, g.D,
+                                            lane, pb > sb0);
+                pb = pe;
+            } while (pb < se0);
         }
     }
+}
+
+// Baum-Welch team path: a hand-off poll that ran out raised *err and the team carried on with stale partial rows;
+// its statistics are not valid, so every output row becomes NaN (the EM path does the same to the
+// log-likelihood in k_reduce_slabs).  Keeps skm_bw_stats asynchronous: no host read of the flag.
+__global__ __launch_bounds__(256) void k_bw_poison(const int *__restrict__ err, double *__restrict__ stat0, long n0,
+                                                   double *__restrict__ stat1, long n1)
+{
+    if (*err == 0) return;
+    const double nan = __builtin_nan("");
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += (long)gridDim.x * blockDim.x) stat0[i] = nan;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += (long)gridDim.x * blockDim.x) stat1[i] = nan;
 }
 
 // Sum the per-wave f64 slabs in a fixed order into out = [N | F | S | llk].
@@ -2786,18 +2848,12 @@ static int check_common(void *ctx, const float *X, long T, int C, int D, const v
     return SKM_OK;
 }
 
-extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, const void *packed, double *out,
-                             int accumulate, void *ws_, size_t ws_bytes, void *stream)
+// E-step with a given plan.  single_sweep_only: the caller's workspace has no room for the T-sized regions of the
+// two-sweep path (plan made with T = 0), so a team launch that cannot be co-resident is an error, not a fallback.
+static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, int D, const void *packed, double *out,
+                     int accumulate, char *ws, bool single_sweep_only, hipStream_t st)
 {
-    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
-    SKM_REQUIRE(ctx != nullptr, "skm_gmm_estep: NULL ctx");
-    Plan p;
-    int rc = make_plan(ctx, T, C, D, true, &p);
-    if (rc) return rc;
-    if ((rc = check_common(ctx_, X, T, C, D, packed, ws_, ws_bytes, p, "skm_gmm_estep"))) return rc;
-    SKM_REQUIRE(out != nullptr, "skm_gmm_estep: out is NULL");
-    hipStream_t st = (hipStream_t)stream;
-    char *ws = static_cast<char *>(ws_);
+    int rc;
     const float *wp = static_cast<const float *>(packed);
     const float *kc = wp + (size_t)p.g.CTpad * p.g.NCH * 256;
     if (p.fused) {
@@ -2882,6 +2938,7 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
         t.S = 0;
         t.C = C;
         t.stat0 = t.stat1 = nullptr;
+        t.debug_drop = 0;
 #ifdef SKM_TRACE
         t.trace = g_trace;
 #endif
@@ -2930,6 +2987,11 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
             return SKM_OK;
         }
         (void)hipGetLastError();   // the teams cannot all be resident on this device: two sweeps instead
+        if (single_sweep_only) {
+            skm_set_error("E-step: the cooperative team launch failed (%s) and the scratch has no room for two sweeps",
+                          hipGetErrorString(le));
+            return SKM_ERR_HIP;
+        }
     }
     if ((rc = launch_lse(ctx, p, X, T, wp, kc, ws, nullptr, st))) return rc;
     StatsArgs a;
@@ -2956,6 +3018,49 @@ extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, c
     }
     SKM_HIP(hipGetLastError());
     return SKM_OK;
+}
+
+extern "C" int skm_gmm_estep(void *ctx_, const float *X, long T, int C, int D, const void *packed, double *out,
+                             int accumulate, void *ws_, size_t ws_bytes, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx != nullptr, "skm_gmm_estep: NULL ctx");
+    Plan p;
+    int rc = make_plan(ctx, T, C, D, true, &p);
+    if (rc) return rc;
+    if ((rc = check_common(ctx_, X, T, C, D, packed, ws_, ws_bytes, p, "skm_gmm_estep"))) return rc;
+    SKM_REQUIRE(out != nullptr, "skm_gmm_estep: out is NULL");
+    return estep_run(ctx, p, X, T, C, D, packed, out, accumulate, static_cast<char *>(ws_), false, (hipStream_t)stream);
+}
+
+// skm_gmm_estep without a workspace argument and without any allocation: the kernels take their scratch (slabs,
+// partials, hand-off rows) from this GPU's copy of the file-scope `scratch` array through SkmCtx::scratch.
+// Shapes served by a single-sweep kernel (C in {256, 512} fused, C in {1024, 2048, 4096} team; D % 4 == 0, D <= 64)
+// need a scratch that does not grow with T; any other shape takes two sweeps whose per-frame partials must fit too,
+// which bounds T.  Everything that must start at zero is cleared on the stream at every call (the array keeps the
+// previous call's contents); calls that overlap on one GPU share the array and race.
+extern "C" size_t skm_gmm_estep_noalloc_max_bytes(void) { return SKM_SCRATCH_BYTES; }
+
+extern "C" int skm_gmm_estep_noalloc(void *ctx_, const float *X, long T, int C, int D, const void *packed, double *out,
+                                     int accumulate, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx != nullptr, "skm_gmm_estep_noalloc: NULL ctx");
+    SKM_REQUIRE(ctx->scratch != nullptr, "skm_gmm_estep_noalloc: no scratch address for device %d", ctx->device);
+    Plan p;
+    int rc = make_plan(ctx, 0, C, D, true, &p);          // layout without the T-sized two-sweep regions
+    if (rc) return rc;
+    const bool single = p.fused || (p.team && p.team_B >= 2);
+    if (!single && (rc = make_plan(ctx, T, C, D, true, &p))) return rc;
+    if (p.total > SKM_SCRATCH_BYTES) {
+        skm_set_error("skm_gmm_estep_noalloc: T=%ld C=%d D=%d needs %zu bytes of scratch, the built-in array holds %zu "
+                      "(use skm_gmm_estep with a workspace)", T, C, D, p.total, (size_t)SKM_SCRATCH_BYTES);
+        return SKM_ERR_WORKSPACE;
+    }
+    if ((rc = check_common(ctx_, X, T, C, D, packed, ctx->scratch, SKM_SCRATCH_BYTES, p, "skm_gmm_estep_noalloc"))) return rc;
+    SKM_REQUIRE(out != nullptr, "skm_gmm_estep_noalloc: out is NULL");
+    return estep_run(ctx, p, X, T, C, D, packed, out, accumulate, static_cast<char *>(ctx->scratch), single,
+                     (hipStream_t)stream);
 }
 
 extern "C" int skm_gmm_loglik(void *ctx_, const float *X, long T, int C, int D, const void *packed, float *loglik,
@@ -3023,6 +3128,10 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
         t.C = C;
         t.stat0 = stat0;
         t.stat1 = stat1;
+        {
+            const char *e = getenv("SKM_DEBUG_TEAM_DROP");
+            t.debug_drop = (e && atoi(e) != 0) ? 1 : 0;
+        }
 #ifdef SKM_TRACE
         t.trace = g_trace;
 #endif
@@ -3059,7 +3168,14 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
 #undef SKM_TEAM_GEO
 #undef SKM_TEAM_LAUNCH
         }
-        if (le == hipSuccess) return SKM_OK;
+        if (le == hipSuccess) {
+            // a timed-out hand-off must not return numbers: consume the flag on the stream
+            SkmProfScope ps(ctx, "k_bw_poison", st);
+            hipLaunchKernelGGL(k_bw_poison, dim3(ctx->cu_count * 4), dim3(256), 0, st, t.err, stat0, (long)S * C, stat1,
+                               (long)S * C * D);
+            SKM_HIP(hipGetLastError());
+            return SKM_OK;
+        }
         (void)hipGetLastError();   // the teams cannot all be resident on this device: two sweeps instead
     }
     if ((rc = launch_lse(ctx, p, X, T, wp, kc, ws, nullptr, st))) return rc;

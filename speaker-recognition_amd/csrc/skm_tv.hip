@@ -418,7 +418,7 @@ static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int
 }
 
 struct TvWs {
-    size_t off_mb, off_linv, off_e, off_tb, off_aux, off_eh32, off_map, off_cs, off_auxs, total;
+    size_t off_mb, off_linv, off_e, off_tb, off_aux, off_eh32, off_map, off_cs, off_auxs, off_y, total;
     int ksplit;
 };
 
@@ -431,7 +431,7 @@ static int tv_ksplit(int cu, long S, int R, int C)
     return ks;
 }
 
-static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0)
+static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0, int D = 0)
 {
     TvWs w;
     const size_t RR = (size_t)R * R;
@@ -455,6 +455,12 @@ static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0)
     w.ksplit = (S > 0 && C > 0) ? tv_ksplit(cu, S, R, C) : 1;
     w.off_auxs = off;
     if (w.ksplit > 1) off += skm_align_up((size_t)w.ksplit * S * R * sizeof(double), 256);
+    // M-step product Y[batch][D][R]: fits the L^-1 region when D <= R, else a region of its own
+    w.off_y = w.off_linv;
+    if (D > R) {
+        w.off_y = off;
+        off += skm_align_up((size_t)batch * D * R * sizeof(double), 256);
+    }
     w.total = off;
     return w;
 }
@@ -463,10 +469,9 @@ extern "C" int skm_tv_naug_stride(int C) { return tv_ldn(C); }
 
 extern "C" size_t skm_tv_workspace_bytes(void *ctx, int C, int D, int R, long S, int batch)
 {
-    (void)D;
     if (R <= 0 || S < 0 || batch <= 0) return 0;
     const int cu = ctx ? static_cast<SkmCtx *>(ctx)->cu_count : 256;
-    return tv_ws(R, S, batch, cu, C).total;
+    return tv_ws(R, S, batch, cu, C, D).total;
 }
 
 extern "C" int skm_tv_whiten(void *ctx_, const void *stat0, const void *stat1, int in_f64, long S, int C, int D,
@@ -516,7 +521,7 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
     SKM_REQUIRE(ctx && naug && ftilde && T32 && G && e_h && ws_, "skm_tv_estep: NULL argument");
     SKM_REQUIRE(S > 0 && C > 0 && D > 0 && R > 0 && batch > 0, "skm_tv_estep: bad shape");
     SKM_REQUIRE((A_aug == nullptr) == (Cacc == nullptr), "skm_tv_estep: A_aug and Cacc go together");
-    const TvWs w = tv_ws(R, S, batch, ctx->cu_count, C);
+    const TvWs w = tv_ws(R, S, batch, ctx->cu_count, C, D);
     if (ws_bytes < w.total) {
         skm_set_error("skm_tv_estep: workspace too small (%zu < %zu)", ws_bytes, w.total);
         return SKM_ERR_WORKSPACE;
@@ -626,14 +631,14 @@ extern "C" int skm_tv_mstep(void *ctx_, double *A_aug, const double *Cacc, int C
     SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
     SKM_REQUIRE(ctx && A_aug && Cacc && F_out && ws_, "skm_tv_mstep: NULL argument");
     SKM_REQUIRE(C > 0 && D > 0 && R > 0 && batch > 0, "skm_tv_mstep: bad shape");
-    const TvWs w = tv_ws(R, 0, batch);
+    const TvWs w = tv_ws(R, 0, batch, 256, 0, D);
     if (ws_bytes < w.total) {
         skm_set_error("skm_tv_mstep: workspace too small (%zu < %zu)", ws_bytes, w.total);
         return SKM_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
     char *ws = static_cast<char *>(ws_);
-    double *Linv = reinterpret_cast<double *>(ws + w.off_linv);
+    double *Ybuf = reinterpret_cast<double *>(ws + w.off_y);
     double *Tb = reinterpret_cast<double *>(ws + w.off_tb);
     const long RR = (long)R * R, CD = (long)C * D;
     int rc;
@@ -642,7 +647,7 @@ extern "C" int skm_tv_mstep(void *ctx_, double *A_aug, const double *Cacc, int C
         // A_c^-1 = X X' with X = U^-1 (upper triangular, left in place of A_c): T_c = (C_c' X) X' is two D x R x R
         // products per component instead of the R^3 product X X' plus one
         if ((rc = blocked_inverse(ctx, A_aug + c0 * RR, nullptr, Tb, nb, R, 0, 0, st))) return rc;
-        double *Y = Linv;   // [nb][D][R]
+        double *Y = Ybuf;   // [nb][D][R]
         GemmArgs g = skm_gemm_args(Cacc + (long)c0 * D, A_aug + c0 * RR, Y, D, R, R, CD, R, R);
         g.transA = 1;       // Y[d][r] = sum_k C[k][cD+d] X[k][r]
         g.ktrim = 1;        // X[k][r] = 0 for k > r

@@ -43,22 +43,55 @@ def shard_bounds(n, k=None, r=None):
     return start, start + base + (1 if r < extra else 0)
 
 
+# Bytes this rank handed to each kind of collective since the last reset (payload = the rank's own contribution).
+# The CPU tests read them to pin the data plane: per-session rows travel as the owner's rows only.
+PAYLOAD = {"all_reduce": 0, "all_gather": 0, "reduce_scatter": 0}
+
+
+def reset_payload():
+    for k in PAYLOAD:
+        PAYLOAD[k] = 0
+
+
+def _nbytes(t):
+    return int(t.numel()) * int(t.element_size())
+
+
 def allreduce_sum_(t):
     """In-place sum over ranks of a torch tensor (device tensor -> RCCL, CPU tensor -> gloo)."""
     if is_dist():
+        PAYLOAD["all_reduce"] += _nbytes(t)
         _td().all_reduce(t)
     return t
 
 
 def allgather_rows(t, counts):
-    """Concatenate per-rank row blocks (rank r contributes counts[r] rows) on every rank."""
+    """Concatenate per-rank row blocks (rank r contributes counts[r] rows) on every rank: the replacement of the
+    reference's Gatherv (sidekit_mpi.py:313-314).  Each rank sends ITS rows only; blocks are padded to the largest
+    count (numpy.array_split shards differ by at most one row) so that one all_gather_into_tensor does it."""
     if not is_dist():
         return t
     import torch
     td = _td()
-    parts = [torch.empty((int(c),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for c in counts]
-    td.all_gather(parts, t.contiguous())
-    return torch.cat(parts, dim=0)
+    counts = [int(c) for c in counts]
+    assert t.shape[0] == counts[rank()], (t.shape, counts, rank())
+    w, m = len(counts), max(counts)
+    tail = tuple(t.shape[1:])
+    if m == 0:
+        return t
+    send = t.contiguous()
+    if t.shape[0] < m:
+        send = torch.zeros((m,) + tail, dtype=t.dtype, device=t.device)
+        send[:t.shape[0]] = t
+    PAYLOAD["all_gather"] += _nbytes(send)
+    out = torch.empty((w * m,) + tail, dtype=t.dtype, device=t.device)
+    if td.get_backend() == "nccl":
+        td.all_gather_into_tensor(out, send)
+    else:
+        td.all_gather(list(out.view((w, m) + tail).unbind(0)), send)
+    if all(c == m for c in counts):
+        return out
+    return torch.cat([out[r * m:r * m + counts[r]] for r in range(w)], dim=0)
 
 
 def reduce_scatter_rows(t):
@@ -73,6 +106,7 @@ def reduce_scatter_rows(t):
     n = t.shape[0] // w
     assert n * w == t.shape[0]
     t = t.contiguous()
+    PAYLOAD["reduce_scatter"] += _nbytes(t)
     if td.get_backend() == "nccl":
         out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         td.reduce_scatter_tensor(out, t)

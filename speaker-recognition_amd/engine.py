@@ -4,9 +4,11 @@ PyTorch is used for device memory, streams and torch.distributed only; every num
 path is produced by the hand-written gfx950 kernels in csrc/.  There is NO CPU fallback: if
 the library or a GPU is missing, constructing a :class:`HipEngine` raises.
 """
+import atexit
 import ctypes
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -35,6 +37,9 @@ SIGNATURES = {
     "skm_gmm_workspace_bytes": (_c_size_t, [_c_void_p, _c_long, _c_int, _c_int]),
     "skm_gmm_estep": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                                _c_void_p, _c_size_t, _c_void_p]),
+    "skm_gmm_estep_noalloc_max_bytes": (_c_size_t, []),
+    "skm_gmm_estep_noalloc": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
+                                       _c_void_p]),
     "skm_gmm_loglik": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p,
                                 _c_void_p, _c_size_t, _c_void_p]),
     "skm_gmm_logprob": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
@@ -75,6 +80,15 @@ SIGNATURES = {
 
 _lib = None
 _lib_lock = threading.Lock()
+_live_engines = weakref.WeakSet()
+
+
+def _close_engines():
+    for e in list(_live_engines):
+        e.close()
+
+
+atexit.register(_close_engines)
 
 
 class SkmError(RuntimeError):
@@ -124,11 +138,28 @@ class HipEngine(object):
         self._ws = None
         self._ws_bytes = 0
 
+        _live_engines.add(self)
+
+    def close(self):
+        """Release the context, its pending timing events and the workspace.  Registered with atexit so that it
+        happens while the HIP runtime is still up (not from __del__ during interpreter shutdown)."""
+        ctx = getattr(self, "ctx", None)
+        if ctx:
+            try:
+                self.torch.cuda.synchronize(self.device)
+                self.lib.skm_prof_enable(ctx, 0)
+                buf = ctypes.create_string_buffer(16384)
+                self.lib.skm_prof_read(ctx, buf, 16384)        # destroys the recorded events
+                self.lib.skm_ctx_destroy(ctx)
+            except Exception:
+                pass
+            self.ctx = None
+        self._ws = None
+        self._ws_bytes = 0
+
     def __del__(self):
         try:
-            if getattr(self, "ctx", None):
-                self.lib.skm_ctx_destroy(self.ctx)
-                self.ctx = None
+            self.close()
         except Exception:
             pass
 
@@ -210,6 +241,18 @@ class HipEngine(object):
         self._check(self.lib.skm_gmm_estep(self.ctx, _c_void_p(X.data_ptr()), T, C, D,
                                            _c_void_p(gmm.packed.data_ptr()), _c_void_p(out.data_ptr()),
                                            1 if accumulate else 0, _c_void_p(ws), need, self._stream()))
+        return out
+
+    def estep_noalloc(self, X, gmm, out, accumulate=False):
+        """skm_gmm_estep_noalloc: the E-step on the library's built-in scratch; `out` must exist (nothing is
+        allocated here either)."""
+        torch = self.torch
+        T, D = X.shape
+        assert D == gmm.D and X.dtype == torch.float32 and X.is_contiguous()
+        assert out.numel() == 2 * gmm.C * D + gmm.C + 1 and out.dtype == torch.float64
+        self._check(self.lib.skm_gmm_estep_noalloc(self.ctx, _c_void_p(X.data_ptr()), T, gmm.C, D,
+                                                   _c_void_p(gmm.packed.data_ptr()), _c_void_p(out.data_ptr()),
+                                                   1 if accumulate else 0, self._stream()))
         return out
 
     def loglik(self, X, gmm):

@@ -116,6 +116,21 @@ class FactorAnalyser(object):
         torch = eng.torch
         fts, naugs, total, local = [], [], 0, []
         for src in sources:
+            res = src.resident_rows() if isinstance(src, StatServer) else None
+            if res is not None:
+                # statistics left in HBM by accumulate_stat(keep_on_device=True), already rounded to float32 as the
+                # file would store them: no host round trip, provided they are exactly this rank's shard
+                n = src.stat0.shape[0]
+                a, b = dist.shard_bounds(n) if dist.is_dist() else (0, n)
+                if np.array_equal(res[0], np.arange(a, b)):
+                    local.append((total + a, total + b))
+                    total += n
+                    if b > a:
+                        ft, naug = eng.tv_whiten(res[1], res[2], ubm.get_mean_super_vector(),
+                                                 ubm.get_invcov_super_vector())
+                        fts.append(ft)
+                        naugs.append(naug)
+                    continue
             _, _, _, _, s0, s1 = _load_stat_arrays(src, prefix)
             n = s0.shape[0]
             a, b = dist.shard_bounds(n) if dist.is_dist() else (0, n)
@@ -268,23 +283,30 @@ class FactorAnalyser(object):
         assert (isinstance(ubm, Mixture) and ubm.validate()), "Second argument must be a proper Mixture"
         eng = self.engine
         tv_rank = self.F.shape[1]
-        modelset, segset, start, stop, _, _ = _load_stat_arrays(stat_server_filename, prefix)
+        if isinstance(stat_server_filename, StatServer):
+            src = stat_server_filename
+            modelset, segset, start, stop = src.modelset, src.segset, src.start, src.stop
+        else:
+            modelset, segset, start, stop, _, _ = _load_stat_arrays(stat_server_filename, prefix)
         nb_sessions = modelset.shape[0]
         ft, naug, total, local = self._resident_stats([stat_server_filename], ubm, prefix)
-        iv = np.zeros((nb_sessions, tv_rank), dtype=STAT_TYPE)
-        iv_sigma = np.zeros((nb_sessions, tv_rank), dtype=STAT_TYPE)
         a, b = local[0]
+        torch = eng.torch
+        width = tv_rank * (2 if uncertainty else 1)
         if ft is not None:
             e_h, sig = self._extract(ft, naug, ubm, 4096, uncertainty)
-            iv[a:b] = eng.to_host(e_h)
-            if sig is not None:
-                iv_sigma[a:b] = eng.to_host(sig)
+            mine = torch.cat([e_h, sig], dim=1) if sig is not None else e_h
+        else:
+            mine = torch.zeros((0, width), dtype=torch.float64, device=getattr(eng, "device", "cpu"))
         if dist.is_dist():
-            torch = eng.torch
-            t = torch.from_numpy(np.concatenate([iv, iv_sigma], axis=1)).to(eng.device)
-            dist.allreduce_sum_(t)                      # every row has exactly one owner
-            both = t.cpu().numpy()
-            iv, iv_sigma = both[:, :tv_rank].copy(), both[:, tv_rank:].copy()
+            # each rank sends the i-vectors of ITS sessions (the Gatherv of sidekit_mpi.py:313-314), S x R doubles
+            # in total; nothing is summed
+            world = dist.world_size()
+            counts = [hi - lo for lo, hi in (dist.shard_bounds(nb_sessions, world, r) for r in range(world))]
+            mine = dist.allgather_rows(mine, counts)
+        both = eng.to_host(mine)
+        iv = np.ascontiguousarray(both[:, :tv_rank])
+        iv_sigma = np.ascontiguousarray(both[:, tv_rank:]) if uncertainty else np.zeros((nb_sessions, tv_rank), dtype=STAT_TYPE)
         iv_server = StatServer()
         iv_server.modelset = np.asarray(modelset)       # stays as stored (bytes), factor_analyser.py:760-761
         iv_server.segset = np.asarray(segset)

@@ -188,6 +188,32 @@ class FeaturesServer(object):
         out, lab_out, out_off = self._post_process_device(X.contiguous(), seg, lab, keep_all)
         return out, out_off.cpu().numpy(), lab_out
 
+    # ------------------------------------------------------------------ what a file holds, without loading it
+    def _labels_after(self, show):
+        """VAD labels of a show as post_processing leaves them (RASTA copies the third label onto the first two,
+        features_server.py:322-323), or None when every frame is labelled."""
+        lab = self.vad.get(show)
+        if lab is None:
+            return None
+        lab = np.asarray(lab, dtype=bool)
+        if self.rasta and lab.shape[0] >= 3:
+            lab = lab.copy()
+            lab[:2] = lab[2]
+        return lab
+
+    def frame_counts(self, show_list, keep_all_features=None):
+        """Rows that load(show)[0] returns for each show under the given (default: current) keep_all_features."""
+        keep_all = self.keep_all_features if keep_all_features is None else keep_all_features
+        out = []
+        for show in show_list:
+            lab = None if keep_all else self._labels_after(show)
+            out.append(int(self.features[show].shape[0]) if lab is None else int(lab.sum()))
+        return out
+
+    def selection_is_identity(self, show_list):
+        """True when keep_all_features = False drops no frame of these shows."""
+        return all(self.frame_counts([s], False) == self.frame_counts([s], True) for s in show_list)
+
     # ------------------------------------------------------------------ the calls of the hot path
     def load(self, show, channel=0, input_feature_filename=None, label=None, start=None, stop=None):
         cep = self.features[show]

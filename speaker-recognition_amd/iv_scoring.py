@@ -23,9 +23,10 @@ def cosine_scoring(enroll, test, ndx, wccn=None, check_missing=True):
     assert isinstance(enroll, StatServer), 'First parameter should be a StatServer'
     assert isinstance(test, StatServer), 'Second parameter should be a StatServer'
     assert isinstance(ndx, Ndx), 'Third parameter should be an Ndx'
-    same = enroll is test
+    # each side is copied and aligned on its own (iv_scoring.py:84-93), also when the same StatServer is passed
+    # twice: models follow modelset order, segments segset order
     enroll_copy = copy.deepcopy(enroll)
-    test_copy = enroll_copy if same else copy.deepcopy(test)
+    test_copy = copy.deepcopy(test)
     clean_ndx = _check_missing_model(enroll_copy, test_copy, ndx) if check_missing else ndx
 
     eng = enroll.engine
@@ -38,6 +39,9 @@ def cosine_scoring(enroll, test, ndx, wccn=None, check_missing=True):
         return eng.row_normalize_(x)
 
     e = prepared(enroll_copy)
+    # one prepared matrix serves both sides only when the two aligned copies hold the same rows in the same order
+    same = enroll is test and enroll_copy.stat1.shape == test_copy.stat1.shape \
+        and np.array_equal(enroll_copy.stat1, test_copy.stat1)
     t = e if same else prepared(test_copy)
     s = eng.to_host(eng.gemm(e, t, transB=True))
 

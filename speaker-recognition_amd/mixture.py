@@ -252,12 +252,26 @@ class Mixture(object):
 
     # ------------------------------------------------------------------ training drivers
     def _resident_frames(self, features_server, feature_list):
-        """All training frames of THIS rank as one float32 tensor in HBM."""
-        feats = features_server.stack_features_parallel(feature_list, num_thread=1)
-        if dist.is_dist() and not getattr(features_server, "is_sharded", False):
+        """All training frames of THIS rank as one float32 tensor in HBM.  In a multi-GPU job the rows of the
+        stacked matrix are cut like numpy.array_split (sidekit_mpi.py:408-410); a server that can tell the frame
+        count of a file without loading it (`frame_counts`) lets every rank load only the files that overlap its
+        row range instead of stacking everything on every host."""
+        if not dist.is_dist() or getattr(features_server, "is_sharded", False):
+            return self._device_frames(features_server.stack_features_parallel(feature_list, num_thread=1))
+        feature_list = list(feature_list)
+        counts = features_server.frame_counts(feature_list) if hasattr(features_server, "frame_counts") else None
+        if counts is None:
+            feats = features_server.stack_features_parallel(feature_list, num_thread=1)
             a, b = dist.shard_bounds(feats.shape[0])
-            feats = feats[a:b]
-        return self._device_frames(feats)
+            return self._device_frames(feats[a:b])
+        off = np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))])
+        a, b = dist.shard_bounds(int(off[-1]))
+        first = int(np.searchsorted(off, a, side="right")) - 1
+        last = int(np.searchsorted(off, b, side="left"))          # files [first, last) overlap rows [a, b)
+        if b <= a:
+            first, last = 0, 1                                    # an empty shard still needs the frame dimension
+        feats = features_server.stack_features_parallel(feature_list[first:last], num_thread=1)
+        return self._device_frames(feats[a - int(off[first]):max(b, a) - int(off[first])] if b > a else feats[:0])
 
     def _global_stats(self, X_dev):
         """E-step on the local shard + all-reduce -> host (N, F, S, llk)."""
@@ -305,12 +319,24 @@ class Mixture(object):
         commented out, mixture.py:711-731)."""
         llk = []
         X_dev = self._init(features_server, feature_list, num_thread)
+        selected = False
 
         for it in iterations[:int(np.log2(distrib_nb))]:
             if save_partial:
                 ext = ".h5" if _has_h5py() else ".npz"
                 self.write('{}_{}g{}'.format(output_file_name, self.get_distrib_nb(), ext), prefix='')
             self._split_ditribution()
+            if not selected:
+                # _init stacks the frames with the server's own keep_all_features setting, but the E-steps of the
+                # reference load every file with keep_all_features = False (mixture.py:585) and leave it False:
+                # with VAD labels they see the labelled frames only
+                selected = True
+                if getattr(features_server, "keep_all_features", False):
+                    features_server.keep_all_features = False
+                    same = getattr(features_server, "selection_is_identity", None)
+                    if not (same is not None and same(feature_list)):
+                        del X_dev
+                        X_dev = self._resident_frames(features_server, feature_list)
             llk.extend(self._em_iterations_device(X_dev, it, ceil_cov, floor_cov))
         return llk
 

@@ -22,17 +22,6 @@ from .mixture import Mixture
 STAT_TYPE = np.float64
 
 
-def sum_log_probabilities(lp):
-    """Kept for API parity (statserver.py:83-95); tiny host helper, not used by the GPU path."""
-    pp_max = np.max(lp, axis=1)
-    log_lk = pp_max + np.log(np.sum(np.exp((lp.transpose() - pp_max).transpose()), axis=1))
-    ind = ~np.isfinite(pp_max)
-    if sum(ind) != 0:
-        log_lk[ind] = pp_max[ind]
-    pp = np.exp((lp.transpose() - log_lk).transpose())
-    return pp, log_lk
-
-
 class StatServer(object):
     def __init__(self, statserver_file_name=None, distrib_nb=0, feature_size=0, index=None, ubm=None,
                  engine=None):
@@ -44,6 +33,7 @@ class StatServer(object):
         self.stat0 = np.array([], dtype=STAT_TYPE)
         self.stat1 = np.array([], dtype=STAT_TYPE)
         self._engine = engine
+        self._resident = None      # device copy of this rank's rows left by accumulate_stat(keep_on_device=True)
 
         if ubm is not None:
             distrib_nb = ubm.w.shape[0]
@@ -77,7 +67,7 @@ class StatServer(object):
     def __deepcopy__(self, memo):
         new = StatServer.__new__(StatServer)
         for k, v in self.__dict__.items():
-            setattr(new, k, v if k == "_engine" else copy.deepcopy(v, memo))
+            setattr(new, k, v if k == "_engine" else (None if k == "_resident" else copy.deepcopy(v, memo)))
         return new
 
     def __repr__(self):
@@ -168,13 +158,21 @@ class StatServer(object):
 
     # ------------------------------------------------------------------ Baum-Welch statistics
     def accumulate_stat(self, ubm, feature_server, seg_indices=None, channel_extension=("", "_b"), num_thread=1,
-                        max_batch_frames=8 * 1024 * 1024):
+                        max_batch_frames=8 * 1024 * 1024, gather=True, keep_on_device=False):
         """Zero and first order statistics of the listed sessions (statserver.py:609-667).
 
         Host side: per session, load frames, cut to [start, stop), keep VAD-selected rows
-        (statserver.py:645-652).  Device side: everything else.  `num_thread` is accepted and
-        ignored; with torch.distributed initialised the sessions are dealt to the ranks like
-        numpy.array_split and the filled rows are summed back (each row has exactly one owner).
+        (statserver.py:645-652).  Device side: everything else.  `num_thread` is accepted and ignored.
+
+        Multi-GPU (torch.distributed initialised): the sessions are dealt to the ranks like numpy.array_split and
+        every rank computes and stores ITS rows only -- there is no reduction on this path (each row has one
+        owner).  `gather=True` (default: every rank returns the reference's full host arrays) then all-gathers the
+        row blocks, each rank sending its own rows; `gather=False` leaves the other ranks' rows untouched
+        (`self.local_rows` lists the rows this rank filled).
+
+        `keep_on_device=True` also keeps this rank's rows in HBM, rounded to float32 as StatServer.write stores
+        them (statserver.py:439-446), so that FactorAnalyser.total_variability / extract_ivectors given this
+        object start from them without a device->host->device round trip (49 GB at 50k sessions x 2048 x 60).
         """
         assert isinstance(ubm, Mixture), 'First parameter has to be a Mixture'
         assert hasattr(feature_server, "load"), 'Second parameter has to be a FeaturesServer'
@@ -192,10 +190,20 @@ class StatServer(object):
         if dist.is_dist():
             a, b = dist.shard_bounds(len(seg_indices))
             mine = seg_indices[a:b]
+        self.local_rows = np.asarray(mine, dtype=np.int64)
+        self._resident = None
 
         eng = self.engine
+        torch = eng.torch
         packed = eng.pack(ubm.w, ubm.mu, ubm.invcov)
         C, D = ubm.distrib_nb(), ubm.dim()
+        kept = []                         # (rows, stat0 f32, stat1 f32) device blocks when keep_on_device
+
+        def store(rows, s0, s1):
+            self.stat0[rows, :] = eng.to_host(s0)
+            self.stat1[rows, :] = eng.to_host(s1)
+            if keep_on_device:
+                kept.append((list(rows), s0.to(torch.float32), s1.to(torch.float32)))
 
         batch, batch_idx, nframes = [], [], 0
 
@@ -206,8 +214,7 @@ class StatServer(object):
             seg_off = np.concatenate([[0], np.cumsum(lens)])
             X = eng.upload_frames(np.concatenate(batch, axis=0) if len(batch) > 1 else batch[0])
             s0, s1 = eng.bw_stats(X, seg_off, packed)
-            self.stat0[batch_idx, :] = eng.to_host(s0)
-            self.stat1[batch_idx, :] = eng.to_host(s1)
+            store(batch_idx, s0, s1)
 
         def show_of(idx):
             show = self.segset[idx]
@@ -232,8 +239,7 @@ class StatServer(object):
                 if not ubm.dim() == X.shape[1]:
                     raise Exception('dimension of ubm and features differ: {:d} / {:d}'.format(ubm.dim(), X.shape[1]))
                 s0, s1 = eng.bw_stats(X, seg_off, packed)
-                self.stat0[take, :] = eng.to_host(s0)
-                self.stat1[take, :] = eng.to_host(s1)
+                store(take, s0, s1)
             mine_loop = []
         else:
             mine_loop = mine
@@ -257,20 +263,51 @@ class StatServer(object):
                 batch, batch_idx, nframes = [], [], 0
         run_batch()
 
-        if dist.is_dist():
-            # every requested row has exactly one owner: zero the others' rows locally, sum over ranks
-            import torch
-            owned = set(mine)
-            others = [i for i in seg_indices if i not in owned]
-            self.stat0[others, :] = 0.0
-            self.stat1[others, :] = 0.0
-            dev = eng.device if hasattr(eng, "device") else "cpu"
-            t0 = torch.as_tensor(self.stat0[seg_indices, :]).to(dev)
-            t1 = torch.as_tensor(self.stat1[seg_indices, :]).to(dev)
-            dist.allreduce_sum_(t0)
-            dist.allreduce_sum_(t1)
-            self.stat0[seg_indices, :] = t0.cpu().numpy()
-            self.stat1[seg_indices, :] = t1.cpu().numpy()
+        if keep_on_device and kept:
+            rows = [r for blk in kept for r in blk[0]]
+            self._resident = {"rows": np.asarray(rows, dtype=np.int64),
+                              "stat0": torch.cat([blk[1] for blk in kept], 0) if len(kept) > 1 else kept[0][1],
+                              "stat1": torch.cat([blk[2] for blk in kept], 0) if len(kept) > 1 else kept[0][2],
+                              "host": (self.stat0, self.stat1)}
+        del kept
+
+        if dist.is_dist() and gather:
+            self._gather_rows(seg_indices)
+
+    def _gather_rows(self, seg_indices, chunk_bytes=1 << 30):
+        """All-gather of the row blocks the ranks own (each rank sends ITS rows, in chunks of about chunk_bytes so
+        the staging buffers stay small); afterwards every rank holds every requested row on the host."""
+        eng = self.engine
+        torch = eng.torch
+        world = dist.world_size()
+        bounds = [dist.shard_bounds(len(seg_indices), world, r) for r in range(world)]
+        a, b = bounds[dist.rank()]
+        dev = getattr(eng, "device", "cpu")
+        for name in ("stat0", "stat1"):
+            arr = getattr(self, name)
+            per = max(1, int(chunk_bytes // max(1, arr.shape[1] * arr.itemsize)))
+            longest = max(hi - lo for lo, hi in bounds)
+            for k0 in range(0, longest, per):
+                spans = [(min(lo + k0, hi), min(lo + k0 + per, hi)) for lo, hi in bounds]
+                la, lb = spans[dist.rank()]
+                local = torch.from_numpy(np.ascontiguousarray(arr[seg_indices[la:lb], :])).to(dev)
+                full = dist.allgather_rows(local, [hi - lo for lo, hi in spans]).cpu().numpy()
+                pos = 0
+                for r, (lo, hi) in enumerate(spans):
+                    if r != dist.rank() and hi > lo:
+                        arr[seg_indices[lo:hi], :] = full[pos:pos + hi - lo]
+                    pos += hi - lo
+
+    def resident_rows(self):
+        """(rows, stat0 float32, stat1 float32) device copy of this rank's rows left by
+        accumulate_stat(keep_on_device=True), or None when there is none or the host arrays were replaced since."""
+        r = self._resident
+        if r is None or r["host"][0] is not self.stat0 or r["host"][1] is not self.stat1:
+            return None
+        return r["rows"], r["stat0"], r["stat1"]
+
+    def release_device(self):
+        self._resident = None
 
     # ------------------------------------------------------------------ small algebra used around the TV path
     def get_mean_stat1(self):

@@ -57,7 +57,23 @@ def _worker(rank, world, port, tmp, q):
         l2 = u2.EM_uniform(gu["cep"], 4)
         out["emu_llk"] = np.abs(np.array(l2) - gu["llk"]).max() / np.abs(gu["llk"]).max()
 
-        # ---- accumulate_stat: sessions sharded, rows summed back
+        # ---- EM_split on files with VAD labels, keep_all_features = True: _init on every frame, E-steps on the
+        # labelled ones; every rank loads only the files that overlap its row range (frame_counts)
+        gv = np.load(os.path.join(GOLDEN, "em_split_vad.npz"))
+        fsv = sk.FeaturesServer(features={"f%d" % i: gv["chunk%d" % i] for i in range(3)},
+                                vad={"f%d" % i: gv["vad%d" % i] for i in range(3)}, keep_all_features=True)
+        loaded = []
+        real_stack = fsv.stack_features_parallel
+        fsv.stack_features_parallel = lambda shows, **kw: (loaded.append(list(shows)), real_stack(shows, **kw))[1]
+        uv = sk.Mixture(engine=eng)
+        lv = uv.EM_split(features_server=fsv, feature_list=["f0", "f1", "f2"], distrib_nb=4)
+        out["emv_llk"] = np.abs(np.array(lv) - gv["llk"]).max() / np.abs(gv["llk"]).max()
+        out["emv_mu"] = np.abs(uv.mu - gv["mu"]).max() / np.abs(gv["mu"]).max()
+        out["emv_flag"] = bool(fsv.keep_all_features)
+        out["emv_loaded"] = loaded
+
+        # ---- accumulate_stat: sessions sharded, every rank computes ITS rows; the row blocks are all-gathered
+        # (no reduction on this path: the payload a rank sends is its own rows)
         ga = np.load(os.path.join(GOLDEN, "accumulate_stat.npz"))
         off = np.concatenate([[0], np.cumsum(ga["lens"])])
         names = ["s%03d" % i for i in range(len(ga["lens"]))]
@@ -67,9 +83,28 @@ def _worker(rank, world, port, tmp, q):
         ub.cov_var_ctl = 1.0 / ub.invcov
         ub._compute_all()
         ss = sk.StatServer(sk.IdMap().set(["m"] * len(names), names), ubm=ub, engine=eng)
-        ss.accumulate_stat(ubm=ub, feature_server=fs, seg_indices=range(len(names)))
+        sk.dist.reset_payload()
+        ss.accumulate_stat(ubm=ub, feature_server=fs, seg_indices=range(len(names)), keep_on_device=True)
         out["bw0"] = np.abs(ss.stat0 - ga["stat0"]).max() / np.abs(ga["stat0"]).max()
         out["bw1"] = np.abs(ss.stat1 - ga["stat1"]).max() / np.abs(ga["stat1"]).max()
+        a, b = sk.dist.shard_bounds(len(names))
+        longest = max(hi - lo for lo, hi in (sk.dist.shard_bounds(len(names), world, r) for r in range(world)))
+        out["bw_payload"] = dict(sk.dist.PAYLOAD)
+        out["bw_payload_expected"] = longest * (ss.stat0.shape[1] + ss.stat1.shape[1]) * 8
+        assert list(ss.local_rows) == list(range(a, b))
+        # gather=False: the rank keeps its shard, nothing travels
+        ss_local = sk.StatServer(sk.IdMap().set(["m"] * len(names), names), ubm=ub, engine=eng)
+        sk.dist.reset_payload()
+        ss_local.accumulate_stat(ubm=ub, feature_server=fs, gather=False)
+        assert sum(sk.dist.PAYLOAD.values()) == 0
+        assert np.array_equal(ss_local.stat1[a:b], ss.stat1[a:b])
+        others = np.ones(len(names), dtype=bool)
+        others[a:b] = False
+        assert not ss_local.stat1[others].any()
+        # the device-resident rows (float32, as a file would store them) feed TV without a host round trip
+        res = ss.resident_rows()
+        assert res is not None and list(res[0]) == list(range(a, b)) and res[2].dtype == torch.float32
+        assert np.array_equal(res[2].numpy(), ss.stat1[a:b].astype(np.float32))
 
         # ---- TV training + extraction: sessions sharded, accumulators all-reduced
         gt = np.load(os.path.join(GOLDEN, "tv.npz"))
@@ -92,8 +127,14 @@ def _worker(rank, world, port, tmp, q):
                              output_file_name=os.path.join(tmp, "tv_r%d" % rank))
         out["tv_F"] = np.abs(fa.F - gt["F_it3_pool"]).max() / np.abs(gt["F_it3_pool"]).max()
         fa.F = gt["F_it3_pool"].copy()
-        ivs = fa.extract_ivectors(ut, stat_file, batch_size=7)
+        sk.dist.reset_payload()
+        ivs, ivsig = fa.extract_ivectors(ut, stat_file, batch_size=7, uncertainty=True)
         out["iv"] = np.abs(ivs.stat1 - gt["iv"]).max() / np.abs(gt["iv"]).max()
+        out["iv_sigma"] = np.abs(ivsig - gt["iv_sigma"]).max() / np.abs(gt["iv_sigma"]).max()
+        out["iv_payload"] = dict(sk.dist.PAYLOAD)
+        out["iv_payload_expected"] = max(hi - lo for lo, hi in (sk.dist.shard_bounds(S, world, r) for r in range(world))) * 2 * 6 * 8
+        ivs1 = fa.extract_ivectors(ut, st, batch_size=7)                 # in-memory StatServer, no uncertainty
+        out["iv_mem"] = np.abs(ivs1.stat1 - gt["iv"]).max() / np.abs(gt["iv"]).max()
         # ---- MAP adaptation + GMM-UBM scoring: test segments sharded, score matrix summed back
         out["sc"], out["map"] = _scoring_case(sk, eng)
         # ---- raw cepstra through the post-processing server (batch path), sessions sharded over ranks
@@ -185,10 +226,19 @@ def test_world2_gloo_matches_single_process(tmp_path):
         # float32 upload of the frames bounds the EM figures; everything after is float64
         assert r["em_llk"] < 1e-5 and r["em_mu"] < 1e-5 and r["em_w"] < 1e-5, r
         assert r["emu_llk"] < 1e-5, r
+        assert r["emv_llk"] < 1e-5 and r["emv_mu"] < 1e-5 and r["emv_flag"] is False, r
         assert r["bw0"] < 1e-5 and r["bw1"] < 1e-5, r
-        assert r["tv_F"] < 1e-5 and r["iv"] < 1e-5, r
+        # Baum-Welch rows: one all-gather of the rank's OWN rows (padded to the longest shard), nothing reduced
+        assert r["bw_payload"]["all_reduce"] == 0 and r["bw_payload"]["reduce_scatter"] == 0, r["bw_payload"]
+        assert r["bw_payload"]["all_gather"] == r["bw_payload_expected"], (r["bw_payload"], r["bw_payload_expected"])
+        assert r["tv_F"] < 1e-5 and r["iv"] < 1e-5 and r["iv_sigma"] < 1e-5 and r["iv_mem"] < 1e-5, r
+        assert r["iv_payload"]["all_reduce"] == 0 and r["iv_payload"]["all_gather"] == r["iv_payload_expected"], r["iv_payload"]
         assert r["sc"] < 1e-4 and r["map"] < 1e-6, r
         assert r["pp0"] < 1e-6 and r["pp1"] < 1e-6, r      # frames pass through float32 on their way to the statistics
+    # shard-aware loading: 453 + 506 + 559 = 1518 frames when every frame is kept -> rank 0 rows [0, 759) touch
+    # files f0, f1 and rank 1 rows [759, 1518) files f1, f2; no rank stacks all three
+    for rank in range(world):
+        assert all(len(l) < 3 for l in res[rank]["emv_loaded"]), res[rank]["emv_loaded"]
     # both ranks hold the same model
     assert abs(res[0]["em_mu"] - res[1]["em_mu"]) < 1e-12
 
@@ -218,3 +268,21 @@ def test_engine_refuses_without_gpu():
         sk.HipEngine()
     with pytest.raises(sk.SkmError):
         sk.Mixture().EM_uniform(np.zeros((100, 4)), 2)
+
+
+@pytest.mark.timeout(180)
+def test_bench_launcher_hands_out_ranks():
+    """`python bench.py --gpus 2` (no torchrun environment) must itself start two fresh rank processes and relay
+    rank 0's JSON line: --launch-check stops each rank after the rendezvous (gloo, no GPU touched)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=170)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    got = json.loads(lines[0])
+    assert got["n_gpus"] == 2
+    assert sorted((r["rank"], r["local_rank"], r["world"]) for r in got["ranks"]) == [(0, 0, 2), (1, 1, 2)]
+    assert len({r["pid"] for r in got["ranks"]}) == 2 and os.getpid() not in {r["pid"] for r in got["ranks"]}

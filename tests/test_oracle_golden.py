@@ -67,6 +67,38 @@ def test_em_split_full_schedule():
     close(gmm.cov_var_ctl, g["ctl"])
 
 
+def test_em_split_with_vad_labels_and_keep_all_features():
+    """_init sees every frame (server setting keep_all_features = True), the E-steps the labelled frames only
+    (mixture.py:585); golden from the real reference through its own post_processing."""
+    g = golden("em_split_vad.npz")
+    every = [g["chunk%d" % i] for i in range(3)]
+    speech = [g["chunk%d" % i][g["vad%d" % i]] for i in range(3)]
+    assert int(g["keep_all_after"]) == 0
+    gmm, llk = orc.em_split(speech, 4, init_chunks=every)
+    assert len(llk) == len(g["llk"]) == 3
+    close(np.array(llk), g["llk"], rtol=1e-9)
+    close(gmm.w, g["w"], rtol=1e-8)
+    close(gmm.mu, g["mu"], rtol=1e-8)
+    close(gmm.invcov, g["invcov"], rtol=1e-8)
+    close(gmm.cov_var_ctl, g["ctl"])
+    # the other reading (E-steps on every frame) is NOT what the reference does
+    gmm2, llk2 = orc.em_split(every, 4)
+    assert np.abs(np.array(llk2) - g["llk"]).max() > 1e-3
+
+
+def test_tv_multi_block_rank():
+    """R = 40 spans two 32-blocks of the device Cholesky; C=64, D=16, 120 sessions, 3 iterations (real reference)."""
+    g = golden("tv_big.npz")
+    C, D, R, S = [int(v) for v in g["shape"]]
+    gmm = orc.GMM(g["w"], g["mu"], g["invcov"])
+    tv_init = 0.1 * np.random.RandomState(7).randn(C * D, R)
+    F3 = orc.total_variability(g["stat0_f32"], g["stat1_f32"], gmm, R, nb_iter=3, tv_init=tv_init, batch_size=30)
+    close(F3, g["F_it3"], rtol=1e-8)
+    iv, iv_sigma = orc.extract_ivectors(g["stat0_f32"], g["stat1_f32"], gmm, g["F_it3"], batch_size=30)
+    close(iv, g["iv"], rtol=1e-9)
+    close(iv_sigma, g["iv_sigma"], rtol=1e-9)
+
+
 def test_em_uniform():
     g = golden("em_uniform.npz")
     init = orc.init_uniform(g["cep"], 4)

@@ -538,8 +538,95 @@ def gen_sliding(sidekit):
     np.savez_compressed(os.path.join(OUT, "post_processing_sliding.npz"), **out)
 
 
+def vad_server(sidekit, table, labels, keep_all_features):
+    """In-memory server that goes through the reference's OWN post_processing (features_server.py:202-246), so
+    that keep_all_features / VAD selection behave exactly as for a file-backed server; stack_features_parallel
+    loads every show with the server's current setting, as the reference's does (features_server.py:634-666)."""
+    class Mem(sidekit.FeaturesServer):
+        def __init__(self):
+            super().__init__(dataset_list=["cep"], keep_all_features=keep_all_features)
+            self.table = table
+
+        def load(self, show, channel=0, input_feature_filename=None, label=None, start=None, stop=None):
+            return self.post_processing(self.table[show].copy(), labels[show].copy())
+
+        def stack_features_parallel(self, show_list, num_thread=1, **kw):
+            return np.vstack([self.load(s)[0] for s in show_list])
+    return Mem()
+
+
+def gen_em_split_vad(sidekit):
+    """EM_split on files WITH VAD labels and keep_all_features=True (model_interface.py:52): _init sees every
+    frame, the E-steps only the labelled ones (mixture.py:585)."""
+    rs = np.random.RandomState(23)
+    D, K = 5, 4
+    centers = rs.randn(K, D) * 6.0
+    chunks, labels = {}, {}
+    for i in range(3):
+        n = 400 + 53 * i
+        lab = rs.randint(0, K, size=n)
+        x = centers[lab] + 0.5 * rs.randn(n, D)
+        vad = rs.rand(n) > 0.4
+        x[~vad] = 0.3 * rs.randn(int((~vad).sum()), D)        # "silence" frames look different
+        chunks["f%d" % i], labels["f%d" % i] = x, vad
+    fs = vad_server(sidekit, chunks, labels, True)
+    ubm = sidekit.Mixture()
+    llk = ubm.EM_split(features_server=fs, feature_list=list(chunks.keys()), distrib_nb=4, num_thread=1,
+                       save_partial=False)
+    out = {"chunk%d" % i: chunks["f%d" % i] for i in range(3)}
+    out.update({"vad%d" % i: labels["f%d" % i] for i in range(3)})
+    out.update(llk=np.array(llk), w=ubm.w, mu=ubm.mu, invcov=ubm.invcov, ctl=ubm.cov_var_ctl,
+               keep_all_after=np.array(int(fs.keep_all_features)))
+    np.savez_compressed(os.path.join(OUT, "em_split_vad.npz"), **out)
+    print("em_split_vad llk", llk[-2:], "iters", len(llk), "keep_all_features after:", fs.keep_all_features)
+
+
+def gen_tv_big(sidekit, tmp):
+    """A TV case whose rank spans several 32-wide blocks of the device Cholesky (R = 40 < C*D, full rank,
+    well conditioned): C=64, D=16, S=120 sessions, 3 EM iterations + extraction.  tv_init is
+    0.1 * RandomState(7).randn(C*D, R) and is regenerated by the test."""
+    C, D, R, S = 64, 16, 40, 120
+    g = orc.random_gmm(C, D, seed=41)
+    ubm = make_ubm(sidekit, g.w, g.mu, g.invcov)
+    rs = np.random.RandomState(42)
+    lens = list(rs.randint(100, 400, size=S))
+    table = {"s%03d" % i: orc.synth_frames(L, dim=D, clusters=16, seed=500 + i, dtype=np.float64)
+             for i, L in enumerate(lens)}
+    fs = mem_server(sidekit, table)
+    idmap = sidekit.IdMap()
+    idmap.leftids = np.array(["spk%d" % (i % 12) for i in range(S)])
+    idmap.rightids = np.array(sorted(table.keys()))
+    idmap.start = np.empty(S, "|O")
+    idmap.stop = np.empty(S, "|O")
+    ss = sidekit.StatServer(idmap, ubm=ubm)
+    ss.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(S), num_thread=1)
+    stat_file = os.path.join(tmp, "stat_big.h5")
+    ss.write(stat_file)
+    tv_init = 0.1 * np.random.RandomState(7).randn(C * D, R)
+    fa = sidekit.FactorAnalyser()
+    fa.total_variability_single(stat_file, ubm, R, nb_iter=3, min_div=True, tv_init=tv_init.copy(),
+                                batch_size=30, save_init=False, output_file_name=None)
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        ivs, iv_sigma = fa.extract_ivectors(ubm, stat_file, prefix="", batch_size=30, uncertainty=True, num_thread=1)
+    finally:
+        os.chdir(cwd)
+    out = dict(w=ubm.w, mu=ubm.mu, invcov=ubm.invcov, stat0_f32=ss.stat0.astype(np.float32),
+               stat1_f32=ss.stat1.astype(np.float32), F_it3=fa.F.copy(), iv=ivs.stat1.copy(),
+               iv_sigma=iv_sigma.copy(), shape=np.array([C, D, R, S]))
+    np.savez_compressed(os.path.join(OUT, "tv_big.npz"), **out)
+    print("tv_big F", fa.F.shape, "|F|max", np.abs(fa.F).max(), "iv", ivs.stat1.shape)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        sidekit = import_reference()
+        gen_em_split_vad(sidekit)
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_tv_big(sidekit, tmp)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "sliding":
         gen_sliding(import_reference())
         return
@@ -569,6 +656,9 @@ def main():
     gen_backend(sidekit)
     gen_sliding(sidekit)
     gen_post_processing(sidekit)
+    gen_em_split_vad(sidekit)
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_tv_big(sidekit, tmp)
 
 
 if __name__ == "__main__":
