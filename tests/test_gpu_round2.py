@@ -118,7 +118,7 @@ def test_em_split_save_partial_and_mixture_read(sk, tmp_path):
     four = sk.Mixture()
     four.read("%s_4g%s" % (base, ext))
     assert four.distrib_nb() == 4 and four.validate() and abs(four.w.sum() - 1.0) < 1e-12
-    out = str(tmp_path / "final" + ext)
+    out = str(tmp_path / ("final" + ext))
     ubm.write(out)
     back = sk.Mixture(out)
     for k in ("w", "mu", "invcov", "cov_var_ctl", "cst", "det"):
