@@ -233,6 +233,12 @@ def main():
         launch_check(world, rank, local_rank)
         return
 
+    if os.environ.get("SKM_DUMP_MAPS"):
+        # where a crash inside exit() handlers lives: the address map as it is when Python's atexit hooks run
+        import atexit
+        import shutil
+        atexit.register(lambda: shutil.copyfile("/proc/self/maps", os.environ["SKM_DUMP_MAPS"]))
+
     import torch
     import torch.distributed as td
     if world > 1:
@@ -699,10 +705,13 @@ def main():
             result["tv"]["cpu_baseline"] = cpu_baseline_tv(2048, D, 400)
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         td.barrier()
         td.destroy_process_group()
+    # release the library context (events, workspace) while the HIP runtime is still up
+    torch.cuda.synchronize()
+    eng.close()
 
 
 if __name__ == "__main__":

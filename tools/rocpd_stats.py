@@ -1,0 +1,25 @@
+"""Kernel statistics of a rocprofv3 run whose output is the rocpd SQLite database (ROCm 7.2 default):
+   python tools/rocpd_stats.py gpurun_out/<dir>/<name>_results.db profiles/<name>_kernel_stats.csv
+Writes name (template arguments kept, argument lists cut), calls, total / average duration in microseconds, share."""
+import csv
+import re
+import sqlite3
+import sys
+
+
+def main():
+    db, out = sys.argv[1], sys.argv[2]
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
+        for name, calls, tot, avg, pct in rows:
+            short = re.sub(r"\(.*$", "", name)
+            short = re.sub(r"^void ", "", short)[:120]
+            w.writerow([short, calls, "%.1f" % (tot / 1e3), "%.2f" % (avg / 1e3), "%.3f" % pct])
+    print("wrote", out, len(rows), "kernels")
+
+
+if __name__ == "__main__":
+    main()
