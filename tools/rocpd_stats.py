@@ -17,7 +17,7 @@ def main():
         for name, calls, tot, avg, pct in rows:
             short = re.sub(r"\(.*$", "", name)
             short = re.sub(r"^void ", "", short)[:120]
-            w.writerow([short, calls, "%.1f" % (tot / 1e3), "%.2f" % (avg / 1e3), "%.3f" % pct])
+            w.writerow([short, calls, "%.1f" % tot, "%.2f" % avg, "%.3f" % pct])
     print("wrote", out, len(rows), "kernels")
 
 
