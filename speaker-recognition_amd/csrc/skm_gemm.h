@@ -47,7 +47,7 @@ struct GemmArgs {
     // XCD-aware tile order: 0 = plain 2-D grid; 1 = the M tiles of one N tile column run back to back on one XCD
     // (they share the B tile in that XCD's L2); 2 = the N tiles of one M tile row do (they share the A tile).
     int swz;
-    int swz_tiles_m, swz_tiles_n;  // set by skm_gemm_launch
+    int swz_tiles_m, swz_tiles_n, swz_batch;  // set by skm_gemm_launch (swz = 3: batched launch, one matrix per XCD at a time)
 };
 
 static inline GemmArgs skm_gemm_args(const void *A, const void *B, void *C, int M, int N, int K, long lda,

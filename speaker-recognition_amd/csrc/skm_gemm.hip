@@ -26,18 +26,24 @@ struct Mf<double> {
 
 // Operand tile loader: BROWS x BK logical tile (row = m or n, col = k), 256 threads, 16-byte vectors along
 // the contiguous dimension of the stored matrix when `vec` (alignment checked on the host).
-//   kfast: the stored matrix is contiguous along k (A not transposed / B transposed), else along the row.
-template <typename TI, int BROWS, int BK>
+//   KFAST: the stored matrix is contiguous along k (A not transposed / B transposed), else along the row.
+// LDS image, chosen so that the global vector goes to LDS as ONE 16-byte store either way:
+//   row-fast operand  T[k][row]   row stride LDT = BROWS + VW   fragments: one scalar read per MFMA k-step
+//   k-fast operand    T[row][k]   row stride LDK = BK + VW      fragments: one 16-byte read per VW k-steps
+// (row strides of 33 / 9 / 5 sixteen-byte units: the lanes of a read or write group fall into distinct banks).
+template <typename TI, int BROWS, int BK, bool KFAST>
 struct TileIO {
     static constexpr int VW = 16 / sizeof(TI);
     static constexpr int NV = BROWS * BK / VW / 256;  // vectors per thread
+    static constexpr int LDT = BROWS + VW, LDK = BK + VW;
+    static constexpr int LDS_ELEMS = KFAST ? BROWS * LDK : BK * LDT;
     typedef TI vec_t __attribute__((ext_vector_type(16 / sizeof(TI))));
 
     // (row, k) of element 0 of vector i of thread tid
-    static __device__ __forceinline__ void coord(int tid, int i, bool kfast, int &row, int &k)
+    static __device__ __forceinline__ void coord(int tid, int i, int &row, int &k)
     {
         const int e = tid + i * 256;
-        if (kfast) {
+        if (KFAST) {
             k = (e % (BK / VW)) * VW;
             row = e / (BK / VW);
         } else {
@@ -46,19 +52,19 @@ struct TileIO {
         }
     }
 
-    // map != nullptr (row-fast layouts only): logical row gr lives at element offset map[gr] of a stored row
-    // (flattened "rows right of the diagonal block" view of an R x R matrix; 4 consecutive logical rows that
-    // start at a multiple of 4 are contiguous when vec is set)
-    static __device__ __forceinline__ void load(TI (&r)[NV * VW], const TI *__restrict__ P, long ld, bool kfast, bool vec,
+    // General (bounds-checked) loader.  map != nullptr (row-fast layouts only): logical row gr lives at element
+    // offset map[gr] of a stored row (flattened "rows right of the diagonal block" view of an R x R matrix; 4
+    // consecutive logical rows that start at a multiple of 4 are contiguous when vec is set)
+    static __device__ __forceinline__ void load(TI (&r)[NV * VW], const TI *__restrict__ P, long ld, bool vec,
                                                int row0, int k0, int rows, int K, int tid,
                                                const int *__restrict__ map = nullptr)
     {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int row, k;
-            coord(tid, i, kfast, row, k);
+            coord(tid, i, row, k);
             const int gr = row0 + row, gk = k0 + k;
-            if (map && !kfast) {
+            if (map && !KFAST) {
                 const TI *pk = P + (long)gk * ld;
                 const bool fullm = gk < K && gr + VW <= rows;
                 if (vec && fullm) {
@@ -71,8 +77,8 @@ struct TileIO {
                 }
                 continue;
             }
-            const TI *p = kfast ? (P + (long)gr * ld + gk) : (P + (long)gk * ld + gr);
-            const bool full = kfast ? (gr < rows && gk + VW <= K) : (gk < K && gr + VW <= rows);
+            const TI *p = KFAST ? (P + (long)gr * ld + gk) : (P + (long)gk * ld + gr);
+            const bool full = KFAST ? (gr < rows && gk + VW <= K) : (gk < K && gr + VW <= rows);
             if (vec && full) {
                 const vec_t v = *reinterpret_cast<const vec_t *>(p);
 #pragma unroll
@@ -80,56 +86,87 @@ struct TileIO {
             } else {
 #pragma unroll
                 for (int j = 0; j < VW; ++j) {
-                    const bool ok = kfast ? (gr < rows && gk + j < K) : (gk < K && gr + j < rows);
+                    const bool ok = KFAST ? (gr < rows && gk + j < K) : (gk < K && gr + j < rows);
                     r[i * VW + j] = ok ? p[j] : (TI)0;
                 }
             }
         }
     }
 
-    // LDS image: T[k][row], row stride LDT
-    static __device__ __forceinline__ void store(const TI (&r)[NV * VW], TI *T, int LDT, bool kfast, int tid)
+    static __device__ __forceinline__ void store(const TI (&r)[NV * VW], TI *T, int tid)
     {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int row, k;
-            coord(tid, i, kfast, row, k);
-            if (kfast) {
+            coord(tid, i, row, k);
+            vec_t v;
 #pragma unroll
-                for (int j = 0; j < VW; ++j) T[(k + j) * LDT + row] = r[i * VW + j];
-            } else {
-                vec_t v;
-#pragma unroll
-                for (int j = 0; j < VW; ++j) v[j] = r[i * VW + j];
-                *reinterpret_cast<vec_t *>(T + k * LDT + row) = v;
-            }
+            for (int j = 0; j < VW; ++j) v[j] = r[i * VW + j];
+            *reinterpret_cast<vec_t *>(KFAST ? (T + row * LDK + k) : (T + k * LDT + row)) = v;
         }
     }
 };
+
+// The k index that lane group lk (= lane / TM) feeds to MFMA step s of a k-tile.  Steps come in groups of VW (the
+// elements of one 16-byte LDS read of a k-fast operand): group q covers k in [q*VW*NLK, (q+1)*VW*NLK), lane
+// group lk owns VW consecutive k of it.  Both operands use the same map, so any order is a valid contraction.
+template <int VW, int NLK>
+__device__ __forceinline__ constexpr int gemm_k_of(int s, int lk)
+{
+    return (s / VW) * (VW * NLK) + lk * VW + (s % VW);
+}
 
 // GUARD: waves test a 4-bit mask before each of their 2 x 2 MFMA blocks and skip the blocks that lie outside the
 // matrix or under the block mask.  Chosen per launch (skm_gemm_launch): it pays when edge or diagonal tiles are a
 // sizeable share of the grid (R = 400 leaves 16 valid columns in the last of its four 128-wide tiles: the aux
 // product went from 7.1 to 4.7 ms) and costs ~6 % on grids of full tiles, which keep the unguarded loop.
-template <typename TI, typename TO, bool ACC64, bool GUARD>
-__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
+// AKF / BKF: the stored A / B is contiguous along k (A not transposed / B transposed).
+//
+// Wave specialisation: a workgroup is 8 waves, two per SIMD.  Waves 0-3 ("compute") only read fragments from LDS and
+// issue MFMAs; waves 4-7 ("staging") only move the next k-tiles global -> registers -> LDS.  The f32 MFMA shares the
+// VALU datapath with every other vector instruction of its own wave (each one between two MFMAs costs matrix-pipe
+// cycles) while a second wave on the SIMD issues beside it for free, so the address arithmetic, loads, LDS stores and
+// their waits live in that second wave.  One raw s_barrier per k-tile joins the two roles; the staging waves wait
+// only for their LDS stores in front of it (never vmcnt(0): the loads of tile kt + 2 stay in flight across it).
+__device__ __forceinline__ void gemm_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename TI, typename TO, bool ACC64, bool GUARD, bool AKF, bool BKF>
+__global__ __launch_bounds__(512, (sizeof(TI) == 4 && ACC64) ? 1 : 2) void k_gemm(GemmArgs g)
 {
     typedef Mf<TI> M;
     constexpr int TM = M::TM, KS = M::KS, NR = M::NR;
     constexpr int BM = 4 * TM, BN = 4 * TM;
     constexpr int BK = (sizeof(TI) == 4 && !ACC64) ? 32 : 16;
-    constexpr int LDT = BM + 16 / sizeof(TI);  // rows stay 16-byte aligned
     constexpr int FOLD = 512 / BK;             // k-tiles between f64 folds (ACC64): every 512 k
-    typedef TileIO<TI, BM, BK> IO;
+    typedef TileIO<TI, BM, BK, AKF> IOA;
+    typedef TileIO<TI, BN, BK, BKF> IOB;
+    constexpr int VW = IOA::VW, NLK = 64 / TM, NSTEP = BK / KS, NGRP = NSTEP / VW;
+    static_assert(KS == NLK && NSTEP % VW == 0, "k map");
+    typedef typename IOA::vec_t vec_t;
 
-    __shared__ __align__(16) TI As[2][BK * LDT];
-    __shared__ __align__(16) TI Bs[2][BK * LDT];
+    __shared__ __align__(16) TI As[2][IOA::LDS_ELEMS];
+    __shared__ __align__(16) TI Bs[2][IOB::LDS_ELEMS];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool staging = wave8 >= 4;
+    const int wave = wave8 & 3, tid = threadIdx.x & 255;     // index inside the role
     const int wm = wave >> 1, wn = wave & 1;
-    const int z = blockIdx.z;
+    int z = blockIdx.z;
     int bx = blockIdx.x, by = blockIdx.y;
-    if (g.swz) {
+    if (g.swz == 3) {
+        // batched launch, 1-D: workgroups w, w + 8, w + 16, ... run on one XCD, so they walk the tiles of ONE matrix
+        // of the batch before the next (XCD x owns matrices x, x + 8, ...): the operand panels that the tiles of a
+        // small matrix share are fetched into one L2 once instead of into all eight
+        const int tiles = g.swz_tiles_m * g.swz_tiles_n, slot = bx >> 3;
+        z = (slot / tiles) * 8 + (bx & 7);
+        if (z >= g.swz_batch) return;
+        const int t = slot % tiles;
+        by = t / g.swz_tiles_n;
+        bx = t % g.swz_tiles_n;
+    } else if (g.swz) {
         // XCD-aware tile order (1-D launch): workgroups w and w + 8 share an XCD and its L2.  Groups of 8 "slow"
         // tile indices (one per XCD) x all "fast" tile indices: the workgroups that an XCD runs back to back
         // walk the fast dimension and re-use the slow dimension's operand tile from that XCD's L2.
@@ -154,10 +191,123 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
     if (n0 >= N || m0 >= g.M) return;
     if (g.tile_mask == 1 && (n0 + BN - 1) / g.mask_blk < m0 / g.mask_blk) return;
     const int Mr = g.M, K = g.K;
-    const bool akfast = !g.transA, bkfast = g.transB != 0;
     const bool avec = (g.vec & 1) != 0, bvec = (g.vec & 2) != 0;
 
-    TI ra[IO::NV * IO::VW], rb[IO::NV * IO::VW];
+    // k range of this tile: all of K unless a triangular operand makes part of it an exact zero (ktrim)
+    int k_begin = 0, k_end = K;
+    if (g.ktrim & 1) k_end = (n0 + BN < K) ? (n0 + BN) : K;
+    if (g.ktrim & 2) k_begin = (m0 > n0) ? m0 : n0;
+    if (g.ktrim & 4) k_begin = n0;
+    if (k_begin > k_end) k_begin = k_end;
+    const int kt0 = k_begin / BK, nk = (k_end + BK - 1) / BK;
+    const int lm = lane % TM, lk = lane / TM;
+
+    if (staging) {
+        // Two tiles are in flight in registers (sets S0 / S1) while tile kt is computed.  Step kt: write tile kt + 1
+        // to the other LDS buffer (whose readers passed the barrier that ended step kt - 1), re-issue that register
+        // set with tile kt + 3, barrier.
+        //
+        // What this loop may cost is set by two measurements.  (1) EVERY vector-ALU instruction issued on a SIMD,
+        // by whichever wave, takes its cycles from the f32 MFMA stream of that SIMD (same datapath): with per-load
+        // 64-bit address arithmetic and per-element selects in here the kernel ran at 0.70 of the MFMA peak, with
+        // the loads removed at 0.91.  So the loop has NO vector arithmetic: buffer loads with a per-lane byte offset
+        // that is fixed for the whole k loop, a buffer descriptor rebuilt per tile by the scalar unit (base advanced,
+        // extent shrunk), and the hardware's range check as the bounds test -- what lies outside the matrix reads as
+        // zero (rows beyond the edge get an offset beyond any extent; k beyond K falls behind the shrinking extent of a
+        // row-fast operand).  (2) hipcc copies the results of loads that sit on two sides of a branch at the join and
+        // waits vmcnt(0) there, right behind their issue: no control flow between a load and its use.
+        // The general loader (vectors that straddle an edge, ragged K of a k-fast operand, extents beyond 32 bits) has
+        // a loop of its own below.
+        const size_t esz = sizeof(TI);
+        const size_t ext_a = AKF ? ((size_t)((Mr - m0 < BM ? Mr - m0 : BM) - 1) * g.lda + K) * esz
+                                 : ((size_t)(K - 1) * g.lda + (Mr - m0)) * esz;
+        const size_t ext_b = BKF ? ((size_t)((N - n0 < BN ? N - n0 : BN) - 1) * g.ldb + K) * esz
+                                 : (g.colmap ? (size_t)K * g.ldb * esz : ((size_t)(K - 1) * g.ldb + (N - n0)) * esz);
+        const bool bpath = avec && bvec && ext_a < 0xE0000000ull && ext_b < 0xE0000000ull &&
+                           (AKF ? (K % BK == 0) : ((Mr - m0) % VW == 0 || m0 + BM <= Mr)) &&
+                           (BKF ? (K % BK == 0) : ((N - n0) % VW == 0 || n0 + BN <= N));
+        if (bpath) {
+            typedef __attribute__((ext_vector_type(4))) int i32x4;
+            vec_t ra[2][IOA::NV], rb[2][IOB::NV];
+            int va[IOA::NV], vb[IOB::NV];            // byte offset of the vector from the tile origin at k-tile 0
+            const TI *A0 = AKF ? (A + (long)m0 * g.lda) : (A + m0);
+            const TI *B0 = BKF ? (B + (long)n0 * g.ldb) : (g.colmap ? B : B + n0);
+#pragma unroll
+            for (int i = 0; i < IOA::NV; ++i) {
+                int row, k;
+                IOA::coord(tid, i, row, k);
+                const long off = AKF ? ((long)row * g.lda + k) : ((long)k * g.lda + row);
+                va[i] = (m0 + row < Mr) ? (int)(unsigned)(off * (long)esz) : (int)0xFFFFFFF0u;
+            }
+#pragma unroll
+            for (int i = 0; i < IOB::NV; ++i) {
+                int row, k;
+                IOB::coord(tid, i, row, k);
+                const bool ok = n0 + row < N;
+                const long off = BKF ? ((long)row * g.ldb + k)
+                                     : ((long)k * g.ldb + (g.colmap ? (long)g.colmap[ok ? n0 + row : 0] : (long)row));
+                vb[i] = ok ? (int)(unsigned)(off * (long)esz) : (int)0xFFFFFFF0u;
+            }
+            const long stepa = (long)BK * (AKF ? 1 : g.lda), stepb = (long)BK * (BKF ? 1 : g.ldb);   // elements per k-tile
+            auto fetch = [&](int kt, vec_t (&qa)[IOA::NV], vec_t (&qb)[IOB::NV]) {
+                const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<TI *>(A0 + kt * stepa), 0, (int)(unsigned)(ext_a - (size_t)(kt * stepa) * esz), 0x00027000);
+                const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<TI *>(B0 + kt * stepb), 0, (int)(unsigned)(ext_b - (size_t)(kt * stepb) * esz), 0x00027000);
+#pragma unroll
+                for (int i = 0; i < IOA::NV; ++i)
+                    qa[i] = __builtin_bit_cast(vec_t, (i32x4)__builtin_amdgcn_raw_buffer_load_b128(rsa, va[i], 0, 0));
+#pragma unroll
+                for (int i = 0; i < IOB::NV; ++i)
+                    qb[i] = __builtin_bit_cast(vec_t, (i32x4)__builtin_amdgcn_raw_buffer_load_b128(rsb, vb[i], 0, 0));
+            };
+            auto put = [&](const vec_t (&qa)[IOA::NV], const vec_t (&qb)[IOB::NV], TI *Ad, TI *Bd) {
+#pragma unroll
+                for (int i = 0; i < IOA::NV; ++i) {
+                    int row, k;
+                    IOA::coord(tid, i, row, k);
+                    *reinterpret_cast<vec_t *>(AKF ? (Ad + row * IOA::LDK + k) : (Ad + k * IOA::LDT + row)) = qa[i];
+                }
+#pragma unroll
+                for (int i = 0; i < IOB::NV; ++i) {
+                    int row, k;
+                    IOB::coord(tid, i, row, k);
+                    *reinterpret_cast<vec_t *>(BKF ? (Bd + row * IOB::LDK + k) : (Bd + k * IOB::LDT + row)) = qb[i];
+                }
+            };
+            fetch(kt0, ra[0], rb[0]);
+            put(ra[0], rb[0], As[0], Bs[0]);
+            if (kt0 + 1 < nk) fetch(kt0 + 1, ra[0], rb[0]);
+            if (kt0 + 2 < nk) fetch(kt0 + 2, ra[1], rb[1]);
+            gemm_barrier();
+            for (int kt = kt0; kt + 1 < nk; kt += 2) {
+                put(ra[0], rb[0], As[1], Bs[1]);             // tile kt + 1
+                if (kt + 3 < nk) fetch(kt + 3, ra[0], rb[0]);
+                gemm_barrier();
+                if (kt + 2 >= nk) break;
+                put(ra[1], rb[1], As[0], Bs[0]);             // tile kt + 2
+                if (kt + 4 < nk) fetch(kt + 4, ra[1], rb[1]);
+                gemm_barrier();
+            }
+            return;
+        }
+        // general loader: one tile in flight, bounds tests per element
+        TI ra[IOA::NV * VW], rb[IOB::NV * VW];
+        IOA::load(ra, A, g.lda, avec, m0, kt0 * BK, Mr, K, tid);
+        IOB::load(rb, B, g.ldb, bvec, n0, kt0 * BK, N, K, tid, g.colmap);
+        IOA::store(ra, As[0], tid);
+        IOB::store(rb, Bs[0], tid);
+        gemm_barrier();
+        for (int kt = kt0; kt + 1 < nk; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            IOA::load(ra, A, g.lda, avec, m0, (kt + 1) * BK, Mr, K, tid);
+            IOB::load(rb, B, g.ldb, bvec, n0, (kt + 1) * BK, N, K, tid, g.colmap);
+            IOA::store(ra, As[cur ^ 1], tid);
+            IOB::store(rb, Bs[cur ^ 1], tid);
+            gemm_barrier();
+        }
+        return;
+    }
 
     typename M::acc_t acc[2][2];
     double acc64[ACC64 ? 2 : 1][ACC64 ? 2 : 1][ACC64 ? NR : 1];
@@ -170,91 +320,67 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
                 acc[mi][ni][r] = 0;
                 if (ACC64) acc64[mi][ni][r] = 0.0;
             }
-
-    // k range of this tile: all of K unless a triangular operand makes part of it an exact zero (ktrim)
-    int k_begin = 0, k_end = K;
-    if (g.ktrim & 1) k_end = (n0 + BN < K) ? (n0 + BN) : K;
-    if (g.ktrim & 2) k_begin = (m0 > n0) ? m0 : n0;
-    if (g.ktrim & 4) k_begin = n0;
-    if (k_begin > k_end) k_begin = k_end;
-    const int kt0 = k_begin / BK, nk = (k_end + BK - 1) / BK;
-    const int lm = lane % TM, lk = lane / TM;
-
-    // Interior tiles (all rows and columns inside the matrix, 16-byte loads legal) take a loader without any
-    // bounds test: one 32-bit element offset per vector, fixed for the whole k loop, on top of a wave-uniform
-    // base pointer that advances by one k-tile per iteration.  Edge tiles and a ragged last k-tile take the
-    // general loader.
-    const bool interior = avec && bvec && m0 + BM <= Mr && n0 + BN <= N;
-    unsigned offa[IO::NV], offb[IO::NV];
-#pragma unroll
-    for (int i = 0; i < IO::NV; ++i) {
-        int row, k;
-        IO::coord(tid, i, akfast, row, k);
-        offa[i] = akfast ? (unsigned)((long)row * g.lda + k) : (unsigned)((long)k * g.lda + row);
-        IO::coord(tid, i, bkfast, row, k);
-        if (bkfast) offb[i] = (unsigned)((long)row * g.ldb + k);
-        else offb[i] = (unsigned)((long)k * g.ldb) + (unsigned)((g.colmap && interior) ? g.colmap[n0 + row] - g.colmap[n0] : row);
-    }
-    const TI *At = akfast ? (A + (long)m0 * g.lda) : (A + m0);                                  // tile origin at k = 0
-    const TI *Bt = bkfast ? (B + (long)n0 * g.ldb) : (B + ((g.colmap && interior) ? g.colmap[n0] : n0));
-    const long inca = akfast ? 1 : g.lda, incb = bkfast ? 1 : g.ldb;                          // elements per unit of k
-    auto load_tile = [&](int kt) {
-        if (interior && (kt + 1) * BK <= K) {
-            const TI *ap = At + (long)kt * BK * inca, *bp = Bt + (long)kt * BK * incb;
-#pragma unroll
-            for (int i = 0; i < IO::NV; ++i) {
-                const typename IO::vec_t va = *reinterpret_cast<const typename IO::vec_t *>(ap + offa[i]);
-                const typename IO::vec_t vb = *reinterpret_cast<const typename IO::vec_t *>(bp + offb[i]);
-#pragma unroll
-                for (int j = 0; j < IO::VW; ++j) {
-                    ra[i * IO::VW + j] = va[j];
-                    rb[i * IO::VW + j] = vb[j];
-                }
-            }
-        } else {
-            IO::load(ra, A, g.lda, akfast, avec, m0, kt * BK, Mr, K, tid);
-            IO::load(rb, B, g.ldb, bkfast, bvec, n0, kt * BK, N, K, tid, g.colmap);
-        }
-    };
     // which of this wave's 2 x 2 MFMA blocks produce anything that the epilogue stores (wave-uniform)
     int need_bits = 15;
     if (GUARD) {
-    need_bits = 0;
+        need_bits = 0;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int bm0 = m0 + wm * 2 * TM + mi * TM, bn0 = n0 + wn * 2 * TM + ni * TM;
+                bool nd = bm0 < Mr && bn0 < N;
+                if (g.tile_mask == 1 && (bn0 + TM - 1) / g.mask_blk < bm0 / g.mask_blk) nd = false;
+                need_bits |= nd ? (1 << (mi * 2 + ni)) : 0;
+            }
+        need_bits = __builtin_amdgcn_readfirstlane(need_bits);
+    }
+
+    // Fragments of one group of VW MFMA steps: fa[mi][j], fb[ni][j] feed step q*VW + j.  A k-fast operand gets them
+    // with one 16-byte LDS read per block, a row-fast one with VW scalar reads.
+    auto read_group = [&](const TI *Ab, const TI *Bb, int q, TI (&fa)[2][VW], TI (&fb)[2][VW]) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            if (AKF) {
+                const vec_t v = *reinterpret_cast<const vec_t *>(Ab + (wm * 2 * TM + mi * TM + lm) * IOA::LDK + q * (VW * NLK) + lk * VW);
+#pragma unroll
+                for (int j = 0; j < VW; ++j) fa[mi][j] = v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < VW; ++j) fa[mi][j] = Ab[(q * (VW * NLK) + lk * VW + j) * IOA::LDT + wm * 2 * TM + mi * TM + lm];
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const int bm0 = m0 + wm * 2 * TM + mi * TM, bn0 = n0 + wn * 2 * TM + ni * TM;
-            bool nd = bm0 < Mr && bn0 < N;
-            if (g.tile_mask == 1 && (bn0 + TM - 1) / g.mask_blk < bm0 / g.mask_blk) nd = false;
-            need_bits |= nd ? (1 << (mi * 2 + ni)) : 0;
+            if (BKF) {
+                const vec_t v = *reinterpret_cast<const vec_t *>(Bb + (wn * 2 * TM + ni * TM + lm) * IOB::LDK + q * (VW * NLK) + lk * VW);
+#pragma unroll
+                for (int j = 0; j < VW; ++j) fb[ni][j] = v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < VW; ++j) fb[ni][j] = Bb[(q * (VW * NLK) + lk * VW + j) * IOB::LDT + wn * 2 * TM + ni * TM + lm];
+            }
         }
-    need_bits = __builtin_amdgcn_readfirstlane(need_bits);
-    }
-    load_tile(kt0);
-    IO::store(ra, As[0], LDT, akfast, tid);
-    IO::store(rb, Bs[0], LDT, bkfast, tid);
-    __syncthreads();
+    };
+
+    // compute waves: inside a k-tile the LDS reads of fragment group q + 1 are issued in front of the MFMAs of group q
+    gemm_barrier();
     int since = 0;
     for (int kt = kt0; kt < nk; ++kt) {
         const int cur = (kt - kt0) & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const TI *Ac = As[cur] + wm * 2 * TM + lm;
-        const TI *Bc = Bs[cur] + wn * 2 * TM + lm;
-        // a wave skips its TM x TM blocks that lie outside the matrix or under the block mask (wave-uniform bits:
-        // R = 400 leaves 16 valid columns in its last 128-wide tile)
+        TI fa[2][2][VW], fb[2][2][VW];
+        read_group(As[cur], Bs[cur], 0, fa[0], fb[0]);
 #pragma unroll
-        for (int kk = 0; kk < BK / KS; ++kk) {
-            TI a[2], b[2];
+        for (int q = 0; q < NGRP; ++q) {
+            if (q + 1 < NGRP) read_group(As[cur], Bs[cur], q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = Ac[(kk * KS + lk) * LDT + mi * TM];
+            for (int j = 0; j < VW; ++j)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = Bc[(kk * KS + lk) * LDT + ni * TM];
+                for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    if (!GUARD || (need_bits & (1 << (mi * 2 + ni)))) acc[mi][ni] = M::mfma(a[mi], b[ni], acc[mi][ni]);
+                    for (int ni = 0; ni < 2; ++ni)
+                        if (!GUARD || (need_bits & (1 << (mi * 2 + ni))))
+                            acc[mi][ni] = M::mfma(fa[q & 1][mi][j], fb[q & 1][ni][j], acc[mi][ni]);
         }
         if (ACC64 && ++since == FOLD) {
             since = 0;
@@ -268,12 +394,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g)
                         acc[mi][ni][r] = 0;
                     }
         }
-        if (kt + 1 < nk) {
-            // the other buffer was last read before the previous barrier: one barrier per k-tile
-            IO::store(ra, As[cur ^ 1], LDT, akfast, tid);
-            IO::store(rb, Bs[cur ^ 1], LDT, bkfast, tid);
-            __syncthreads();
-        }
+        if (kt + 1 < nk) gemm_barrier();   // the reads of this buffer end here; the staging waves overwrite it next
     }
 
     // epilogue
@@ -315,8 +436,13 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
     const int ncols = g.tri_n > 0 ? g.tri_n : g.N;
     dim3 grid((ncols + tile - 1) / tile, (g.M + tile - 1) / tile, batch);
     SKM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm(%s): grid too large", tag);
-    int swz_tm = 0, swz_tn = 0;
-    if (g.swz) {
+    int swz_tm = 0, swz_tn = 0, swz_mode = g.swz;
+    if (!g.swz && batch >= 16 && g.tri_n == 0) {
+        swz_mode = 3;
+        swz_tm = (int)grid.y;
+        swz_tn = (int)grid.x;
+        grid = dim3((unsigned)(swz_tm * swz_tn) * (unsigned)((batch + 7) / 8 * 8), 1, 1);
+    } else if (g.swz) {
         SKM_REQUIRE(g.tri_n == 0 && (g.swz == 1 || g.swz == 2), "gemm(%s): bad swizzle", tag);
         swz_tm = (int)grid.y;
         swz_tn = (int)grid.x;
@@ -326,6 +452,8 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
     SKM_REQUIRE(!g.colmap || (!g.transB && g.tile_mask == 0 && g.tri_n == 0), "gemm(%s): colmap needs plain B", tag);
     const size_t esz = (kind == SKM_GEMM_F64_F64 || kind == SKM_GEMM_F64_F32OUT) ? 8 : 4;
     GemmArgs gv = g;
+    gv.swz = swz_mode;
+    gv.swz_batch = batch;
     gv.swz_tiles_m = swz_tm;
     gv.swz_tiles_n = swz_tn;
     gv.vec = (vec_ok(g.A, g.lda, g.sA, 0, 0, esz) ? 1 : 0) |
@@ -341,10 +469,17 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
                          (g.tile_mask == 1 ? 1.0 / (tiles_m < tiles_n ? tiles_m : tiles_n) : 0.0);
     const bool guard = share >= 0.10 || g.tri_n > 0;
     SkmProfScope ps(ctx, tag, st);
-#define SKM_GEMM_GO(TI_, TO_, ACC_)                                                                   \
-    do {                                                                                               \
-        if (guard) hipLaunchKernelGGL((k_gemm<TI_, TO_, ACC_, true>), grid, dim3(256), 0, st, gv);     \
-        else hipLaunchKernelGGL((k_gemm<TI_, TO_, ACC_, false>), grid, dim3(256), 0, st, gv);          \
+#define SKM_GEMM_L(TI_, TO_, ACC_, G_)                                                                          \
+    do {                                                                                                             \
+        if (!g.transA && !g.transB) hipLaunchKernelGGL((k_gemm<TI_, TO_, ACC_, G_, true, false>), grid, dim3(512), 0, st, gv);      \
+        else if (g.transA && !g.transB) hipLaunchKernelGGL((k_gemm<TI_, TO_, ACC_, G_, false, false>), grid, dim3(512), 0, st, gv); \
+        else if (!g.transA && g.transB) hipLaunchKernelGGL((k_gemm<TI_, TO_, ACC_, G_, true, true>), grid, dim3(512), 0, st, gv);   \
+        else hipLaunchKernelGGL((k_gemm<TI_, TO_, ACC_, G_, false, true>), grid, dim3(512), 0, st, gv);              \
+    } while (0)
+#define SKM_GEMM_GO(TI_, TO_, ACC_)                    \
+    do {                                               \
+        if (guard) SKM_GEMM_L(TI_, TO_, ACC_, true);   \
+        else SKM_GEMM_L(TI_, TO_, ACC_, false);        \
     } while (0)
     switch (kind) {
     case SKM_GEMM_F32_F32: SKM_GEMM_GO(float, float, false); break;
@@ -355,6 +490,7 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
     default: skm_set_error("gemm(%s): unknown kind %d", tag, kind); return SKM_ERR_ARG;
     }
 #undef SKM_GEMM_GO
+#undef SKM_GEMM_L
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }

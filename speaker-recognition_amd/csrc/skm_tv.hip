@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void k_tv_whiten(const TS *__restrict__ stat0,
 // Column map of the flattened upper-block view of an R x R matrix: for row z (block b = z / 32) the logical
 // columns start(z) .. start(z) + R - 32 b - 1 map to element offsets z*R + 32 b + j.
 #define TV_CS_SPLIT 16   // session ranges of the e_hh column sums
+#define TV_AUX_CHUNK 2048 // k per float32 accumulation run of the aux product (float64 across runs)
 static inline long tv_tri_cols(int R)
 {
     long n = 0;
@@ -545,23 +546,34 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         hipLaunchKernelGGL(k_tri_map, dim3(R), dim3(256), 0, st, cmap, R);
     }
     SKM_HIP(hipGetLastError());
-    // aux = f~ T for every session (factor_analyser.py:88); split over K (component blocks) when S is small
+    // aux = f~ T for every session (factor_analyser.py:88): K = C*D is long (122 880), so the float32 MFMA sums run
+    // over chunks of TV_AUX_CHUNK k (plain k loop, no float64 registers: the fast instantiation) and the chunks are
+    // added in float64 -- in the output itself (beta = 1) when there are enough output tiles to fill the chip, in
+    // split-K slabs when S is small.
     if (w.ksplit > 1) {
         double *slabs = reinterpret_cast<double *>(ws + w.off_auxs);
         const long kc = CD / w.ksplit;
-        GemmArgs g = skm_gemm_args(ftilde, T32, slabs, (int)S, R, (int)kc, CD, R, R);
-        g.sA = kc;
-        g.sB = kc * R;
-        g.sC = S * R;
-        g.swz = 2;          // the R/128 column tiles share the f~ row tile
-        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, g, w.ksplit, st, "k_gemm_aux"))) return rc;
+        for (long k0 = 0; k0 < kc; k0 += TV_AUX_CHUNK) {
+            const int kn = (int)((kc - k0) < TV_AUX_CHUNK ? (kc - k0) : TV_AUX_CHUNK);
+            GemmArgs g = skm_gemm_args(ftilde + k0, T32 + k0 * R, slabs, (int)S, R, kn, CD, R, R);
+            g.sA = kc;
+            g.sB = kc * R;
+            g.sC = S * R;
+            g.beta = k0 ? 1.0 : 0.0;
+            g.swz = 2;          // the R/128 column tiles share the f~ row tile
+            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, g, w.ksplit, st, "k_gemm_aux"))) return rc;
+        }
         SkmProfScope ps(ctx, "k_sum_slabs", st);
         hipLaunchKernelGGL(k_sum_slabs, dim3(ctx->cu_count * 2), dim3(256), 0, st, aux, slabs, S * R, w.ksplit);
         SKM_HIP(hipGetLastError());
     } else {
-        GemmArgs g = skm_gemm_args(ftilde, T32, aux, (int)S, R, (int)CD, CD, R, R);
-        g.swz = 2;
-        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, g, 1, st, "k_gemm_aux"))) return rc;
+        for (long k0 = 0; k0 < CD; k0 += TV_AUX_CHUNK) {
+            const int kn = (int)((CD - k0) < TV_AUX_CHUNK ? (CD - k0) : TV_AUX_CHUNK);
+            GemmArgs g = skm_gemm_args(ftilde + k0, T32 + k0 * R, aux, (int)S, R, kn, CD, R, R);
+            g.beta = k0 ? 1.0 : 0.0;
+            g.swz = 2;
+            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, g, 1, st, "k_gemm_aux"))) return rc;
+        }
     }
     for (long b0 = 0; b0 < S; b0 += batch) {
         const int nb = (int)((S - b0) < batch ? (S - b0) : batch);
@@ -571,7 +583,9 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         l.colmap = cmap;
         l.colmap_vec = (R % 4 == 0);
         l.swz = 1;          // the session tiles of one G column tile share it in one XCD's L2
-        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64ACC, l, 1, st, "k_gemm_lbuild"))) return rc;
+        // K = C float32 MFMA terms per entry, accumulated in float32 like the <= `batch` terms of the A accumulation
+        // below (the operands are float32 already; ~sqrt(C) * 6e-8 on top of their rounding), stored as float64
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, l, 1, st, "k_gemm_lbuild"))) return rc;
         const bool solve_only = !train && !iv_sigma;
         if ((rc = blocked_inverse(ctx, Mb, train ? Linv : nullptr, Tb, nb, R, 1, 1, st, solve_only))) return rc;
         if (solve_only) {
