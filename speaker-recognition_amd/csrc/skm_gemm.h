@@ -79,3 +79,4 @@ static inline GemmArgs skm_gemm_args(const void *A, const void *B, void *C, int 
 //   SKM_GEMM_F64_F64     A,B double, C double
 //   SKM_GEMM_F64_F32OUT  A,B double, C float
 int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStream_t st, const char *tag);
+
