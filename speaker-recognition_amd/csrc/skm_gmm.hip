@@ -800,6 +800,7 @@ struct FusedArgs {
     double *slabs;     // [n_blocks][NWV] slabs of [64][NF*32] f64 (zeroed by the host)
     double *llk_part;  // [n_blocks]
     int stagger;       // 0 lock-step, 1 second half of the waves runs half a tile late, 2 and at priority 1
+    int flush_tiles;   // frame tiles accumulated in f32 between two folds into the f64 slab
 #ifdef SKM_TRACE
     long long *trace;  // [NWV][16] cycle stamps of one tile of block 1 (tools/trace_estep.py)
 #endif
@@ -1205,8 +1206,13 @@ __device__ __forceinline__ void wset_mma_pf(f32x16 (&lg)[NCT], const WSet<NCT> &
 template <int NCT>
 __device__ __forceinline__ void vgpr_settle_all(f32x16 (&lg)[NCT])
 {
-    static_assert(NCT == 4, "operand list is written for four accumulators");
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lg[0]), "+v"(lg[1]), "+v"(lg[2]), "+v"(lg[3]));
+    static_assert(NCT == 1 || NCT == 2 || NCT == 4, "operand lists are written for 1, 2 or 4 accumulators");
+    if constexpr (NCT == 4)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lg[0]), "+v"(lg[1]), "+v"(lg[2]), "+v"(lg[3]));
+    else if constexpr (NCT == 2)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lg[0]), "+v"(lg[1]));
+    else
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lg[0]));
 }
 
 // mixed tail group (held in wl) with the loads of pair 0 for the next tile spread between the MFMAs.
@@ -1318,7 +1324,8 @@ __device__ __forceinline__ void gemm_stats_agpr(f32x16 (&acc)[NCT][NJT * (WITH_S
     }
 }
 
-template <int NCT, int NF>
+// STORE: the first flush of a wave writes its slab instead of adding to it (no memset, no read)
+template <int NCT, int NF, bool STORE = false>
 __device__ __forceinline__ void flush_slab_agpr(f32x16 (&acc)[NCT][NF], double *slab_lane)
 {
     constexpr int NFW = NF * 32;
@@ -1331,7 +1338,7 @@ __device__ __forceinline__ void flush_slab_agpr(f32x16 (&acc)[NCT][NF], double *
             const f32x16 v = acc[ct][jf];
             double old[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) old[r] = p[acc_row(r, 0) * NFW];
+            for (int r = 0; r < 16; ++r) old[r] = STORE ? 0.0 : p[acc_row(r, 0) * NFW];
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[acc_row(r, 0) * NFW] = old[r] + (double)v[r];
 #pragma unroll
@@ -1461,8 +1468,8 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
 
     SKM_TRACE_DECL;
     int cur = 0;
-    for (long base = ta; base < tb; base += SKM_FLUSH_TILES) {
-    const long end = (base + SKM_FLUSH_TILES < tb) ? base + SKM_FLUSH_TILES : tb;
+    for (long base = ta; base < tb; base += a.flush_tiles) {
+    const long end = (base + a.flush_tiles < tb) ? base + a.flush_tiles : tb;
 #pragma unroll 1
     for (long tile = base; tile < end; ++tile) {
         const long t0 = tile << 5;
@@ -1571,13 +1578,224 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
         cur = nxt;
     }
     // the accumulators are touched by nothing but the asm MFMAs inside the tile loop, so they stay in AGPRs
-    flush_slab_agpr<NCT, NF>(acc, slab_lane);
+    if (base == ta)
+        flush_slab_agpr<NCT, NF, true>(acc, slab_lane);
+    else
+        flush_slab_agpr<NCT, NF, false>(acc, slab_lane);
     }
+    if (ta >= tb) flush_slab_agpr<NCT, NF, true>(acc, slab_lane);   // empty range: the slab must still read as zero
     if (wave == 0) {
 #pragma unroll
         for (int msk = 1; msk < 32; msk <<= 1) llk_lane += __shfl_xor(llk_lane, msk);
         if (lane == 0) a.llk_part[blockIdx.x] = llk_lane * 0.6931471805599453094;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Single-sweep E-step for C <= 128 (the first seven stages of EM_split): ONE wave holds every component
+// (NCT = 1, 2 or 4 tiles of 32), so each wave is a workgroup of its own that walks its own range of frame
+// tiles -- no cross-wave exchange, no workgroup barrier, and the posterior normalisation is exact inside
+// the wave.  Same building blocks as k_estep_fat (W streamed through buffer loads, statistics in AGPRs,
+// f64 slab per wave).  The frame ring has two slots: a single in-order wave has finished reading slot
+// cur^1 (statistics GEMM of the previous tile) before it stages the next tile there.  NCT = 1 leaves
+// room for two waves per SIMD, which hides the LDS / settle / HBM waits of one wave behind the MFMAs of
+// the other.
+// ------------------------------------------------------------------------------------------------
+template <int NCT, int NJT, int GEO>
+__global__ __launch_bounds__(64, 1) void k_estep_solo(FusedArgs a)
+{
+    constexpr int NF = 2 * NJT, NFW = NF * 32, PRE = 32;
+    extern __shared__ __align__(16) float smem[];
+    const int lane = threadIdx.x;
+    const int h = lane >> 5, c = lane & 31;
+    const TileGeom g = a.g;
+    const int tile_floats = 32 * g.XS;
+
+    float *xs = smem;                       // [2][32][XS]
+    float *ls = xs + 2 * tile_floats;       // [2][32]: per-frame maximum, per-frame 1/sum
+
+    {
+        const int padw = g.XS - g.D;
+        for (int i = lane; i < 2 * 32 * padw; i += 64) {
+            const int row = i / padw, col = g.D + (i - row * padw);
+            xs[row * g.XS + col] = (col == g.D) ? 1.0f : 0.0f;
+        }
+    }
+    float kcv[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) kcv[ct] = a.kc[ct * 32 + c];
+    WStream Wg4;
+    Wg4.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp), 0, NCT * g.NG * 1024, 0x00027000);
+    Wg4.voff = lane * 16;
+    Wg4.sbase = 0;
+
+    f32x16 acc[NCT][NF];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int jf = 0; jf < NF; ++jf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
+
+    const long tiles = (a.T + 31) >> 5;
+    const long ta = tiles * blockIdx.x / gridDim.x, tb = tiles * (blockIdx.x + 1) / gridDim.x;
+    double *slab_lane = a.slabs + (long)blockIdx.x * (long)(NCT * 32 * NFW) + (4 * h) * NFW + c;
+    double llk_lane = 0.0;
+
+    // staging of the contiguous 32*D span of a tile: 32 floats per lane (host: 32*D <= 2048)
+    constexpr int NST = PRE / 4;
+    float pre[PRE];
+    int st_row[NST], st_dst[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int e = lane + i * 64;
+        const int n4 = g.D >> 2;
+        const int row = g.vec4 ? e / n4 : 0;
+        st_row[i] = (g.vec4 && e < 32 * n4) ? row : 1 << 20;
+        st_dst[i] = row * g.XS + 4 * (e - row * n4);
+    }
+    auto load_pre = [&](long t0, int nvalid) __attribute__((always_inline)) {
+        if (g.vec4) {
+            const f32x4 *X4 = reinterpret_cast<const f32x4 *>(a.X + t0 * (long)g.D);
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (st_row[i] < nvalid) v = X4[lane + i * 64];
+                pre[4 * i + 0] = v[0];
+                pre[4 * i + 1] = v[1];
+                pre[4 * i + 2] = v[2];
+                pre[4 * i + 3] = v[3];
+            }
+        } else {
+            const float *Xs = a.X + t0 * (long)g.D;
+            const int n_el = 32 * g.D;
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) {
+                const int e = lane + i * 64;
+                pre[i] = (e < n_el && e / g.D < nvalid) ? Xs[e] : 0.f;
+            }
+        }
+    };
+    auto store_pre = [&](float *dst) __attribute__((always_inline)) {
+        if (g.vec4) {
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                if (st_row[i] < 32) {
+                    f32x4 v = {pre[4 * i], pre[4 * i + 1], pre[4 * i + 2], pre[4 * i + 3]};
+                    *reinterpret_cast<f32x4 *>(dst + st_dst[i]) = v;
+                }
+            }
+        } else {
+            const int n_el = 32 * g.D;
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) {
+                const int e = lane + i * 64;
+                if (e < n_el) {
+                    const int row = e / g.D;
+                    dst[row * g.XS + (e - row * g.D)] = pre[i];
+                }
+            }
+        }
+    };
+    auto valid_in = [&](long t0) __attribute__((always_inline)) { return (int)((a.T - t0) < 32 ? (a.T - t0) : 32); };
+
+    if (ta < tb) {
+        const long t0 = ta << 5;
+        load_pre(t0, valid_in(t0));
+        store_pre(xs);
+        if (ta + 1 < tb) load_pre(t0 + 32, valid_in(t0 + 32));
+    }
+    WSet<NCT> wa;
+    wset_load<NCT>(wa, Wg4, g.NG, g.NP, 0);
+    wave_lds_fence();
+
+    const int frame = acc_row((c >> 1) & 15, h);
+    bool first = true;
+    int cur = 0;
+    for (long base = ta; base < tb; base += a.flush_tiles) {
+    const long end = (base + a.flush_tiles < tb) ? base + a.flush_tiles : tb;
+#pragma unroll 1
+    for (long tile = base; tile < end; ++tile) {
+        const int nvalid = valid_in(tile << 5);
+        const float *xt = xs + cur * tile_floats;
+
+        f32x16 lg[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            float k = kcv[ct];
+            asm volatile("" : "+v"(k));     // see k_estep_fat: keeps the splat inside the loop
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lg[ct][r] = k;
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
+        gemm_logits_fat<NCT, GEO>(lg, wa, xt + c * g.XS, h, Wg4, g);
+
+        // exact per-frame maximum over all components, e = 2^(l - max), per-frame sum of e
+        float m[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            m[r] = lg[0][r];
+#pragma unroll
+            for (int ct = 1; ct < NCT; ++ct) m[r] = __builtin_fmaxf(m[r], lg[ct][r]);
+        }
+        lane_reduce16(m, c, OpMax());
+        if ((c & 1) == 0) ls[frame] = m[0];
+        wave_lds_fence();
+        float sm[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float acc1 = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const float e = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + i] - m4[i]);
+                    lg[ct][4 * q4 + i] = e;
+                    acc1 += e;
+                }
+                sm[4 * q4 + i] = acc1;
+            }
+        }
+        lane_reduce16(sm, c, OpAdd());
+        if ((c & 1) == 0) {
+            const bool valid = frame < nvalid;
+            ls[32 + frame] = valid ? __builtin_amdgcn_rcpf(sm[0]) : 0.f;
+            if (valid) llk_lane += (double)(m[0] + __builtin_amdgcn_logf(sm[0]));
+        }
+        // next tile goes to the other slot: its last reader was the previous tile's statistics GEMM
+        if (tile + 1 < tb) store_pre(xs + (cur ^ 1) * tile_floats);
+        wave_lds_fence();
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 f4 = *reinterpret_cast<const f32x4 *>(ls + 32 + 8 * q4 + 4 * h);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                lg[ct][4 * q4 + 0] *= f4[0];
+                lg[ct][4 * q4 + 1] *= f4[1];
+                lg[ct][4 * q4 + 2] *= f4[2];
+                lg[ct][4 * q4 + 3] *= f4[3];
+            }
+        }
+        // frames of tile+2 are requested in front of the statistics GEMM, which has no vector-memory wait
+        if (tile + 2 < tb) load_pre((tile + 2) << 5, valid_in((tile + 2) << 5));
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
+        gemm_stats_agpr<NJT, NCT>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
+        wave_lds_fence();
+        cur ^= 1;
+    }
+    if (first)
+        flush_slab_agpr<NCT, NF, true>(acc, slab_lane);
+    else
+        flush_slab_agpr<NCT, NF, false>(acc, slab_lane);
+    first = false;
+    }
+    if (first) flush_slab_agpr<NCT, NF, true>(acc, slab_lane);   // empty range: the slab must still read as zero
+#pragma unroll
+    for (int msk = 1; msk < 64; msk <<= 1) llk_lane += __shfl_xor(llk_lane, msk);
+    if (lane == 0) a.llk_part[blockIdx.x] = llk_lane * 0.6931471805599453094;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2326,59 +2544,83 @@ __global__ __launch_bounds__(256) void k_bw_poison(const int *__restrict__ err, 
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += (long)gridDim.x * blockDim.x) stat1[i] = nan;
 }
 
-// Sum the per-wave f64 slabs in a fixed order into out = [N | F | S | llk].
+// Sum the per-wave f64 slabs in a fixed order into out = [N | F | S | llk].  A workgroup covers 16 consecutive
+// outputs with 16 threads each: thread (o, q) sums slots q, q+16, ... (8 loads in flight, combined in a fixed
+// order), the 16 partial sums meet in LDS.  Workgroup 0 also sums the log-likelihood partials the same way.
+#define SKM_RED_OUT 16
 __global__ __launch_bounds__(256) void k_reduce_slabs(const double *__restrict__ slabs, int n_cb, int n_fs, int NW,
                                                       int NCT, int NJT, int NF, int C, int D,
                                                       double *__restrict__ out, int accumulate,
                                                       const double *__restrict__ llk_part, int n_llk,
                                                       const int *__restrict__ err = nullptr)
 {
-    const int NFW = NF * 32;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx == 0) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
         double l = 0.0;
-        for (int i = 0; i < n_llk; ++i) l += llk_part[i];
-        if (err && *err) l = __builtin_nan("");   // a team hand-off timed out: the statistics are not valid
-        double *p = out + C + 2L * C * D;
-        *p = accumulate ? (*p + l) : l;
+        for (int i = tid; i < n_llk; i += 256) l += llk_part[i];
+        red[tid] = l;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            l = red[0];
+            if (err && *err) l = __builtin_nan("");   // a team hand-off timed out: the statistics are not valid
+            double *p = out + C + 2L * C * D;
+            *p = accumulate ? (*p + l) : l;
+        }
+        __syncthreads();
     }
+    const int NFW = NF * 32;
+    const int o = tid & (SKM_RED_OUT - 1), q0 = tid / SKM_RED_OUT;
+    constexpr int NQ = 256 / SKM_RED_OUT;
+    const long idx = (long)blockIdx.x * SKM_RED_OUT + o;
     const int comp = (int)(idx / NFW), col = (int)(idx - (long)comp * NFW);
-    if (comp >= C) return;
-    double *dst;
-    if (col < NJT * 32) {
-        if (col < D)
-            dst = out + C + (long)comp * D + col;
-        else if (col == D)
-            dst = out + comp;
-        else
-            return;
-    } else {
-        const int d = col - NJT * 32;
-        if (d >= D) return;
-        dst = out + C + (long)C * D + (long)comp * D + d;
-    }
-    const int cb = (comp >> 5) / NCT;
-    const int cl = comp - cb * NCT * 32;
-    const long slab_elems = (long)NCT * 32 * NFW;
-    // slot (fs, w) of this component block lives at ((fs * n_cb + cb) * NW + w); 8 partial sums keep 8 loads in
-    // flight, always combined in the same order (bit-identical runs)
-    const double *src = slabs + (long)cl * NFW + col;
-    const int n_slots = n_fs * NW;
-    double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int i = 0;
-    for (; i + 8 <= n_slots; i += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int q = i + u, fs = q / NW, w = q - fs * NW;
-            part[u] += src[(((long)fs * n_cb + cb) * NW + w) * slab_elems];
+    double *dst = nullptr;
+    if (comp < C) {
+        if (col < NJT * 32) {
+            if (col < D)
+                dst = out + C + (long)comp * D + col;
+            else if (col == D)
+                dst = out + comp;
+        } else {
+            const int d = col - NJT * 32;
+            if (d < D) dst = out + C + (long)C * D + (long)comp * D + d;
         }
     }
-    for (; i < n_slots; ++i) {
-        const int fs = i / NW, w = i - fs * NW;
-        part[i & 7] += src[(((long)fs * n_cb + cb) * NW + w) * slab_elems];
+    double sum = 0.0;
+    if (dst) {
+        const int cb = (comp >> 5) / NCT;
+        const int cl = comp - cb * NCT * 32;
+        const long slab_elems = (long)NCT * 32 * NFW;
+        // slot (fs, w) of this component block lives at ((fs * n_cb + cb) * NW + w)
+        const double *src = slabs + (long)cl * NFW + col;
+        const int n_slots = n_fs * NW;
+        double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int i = q0;
+        for (; i + 7 * NQ < n_slots; i += 8 * NQ) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = i + u * NQ, fs = q / NW, w = q - fs * NW;
+                part[u] += src[(((long)fs * n_cb + cb) * NW + w) * slab_elems];
+            }
+        }
+        for (int u = 0; i < n_slots; i += NQ, ++u) {
+            const int fs = i / NW, w = i - fs * NW;
+            part[u] += src[(((long)fs * n_cb + cb) * NW + w) * slab_elems];
+        }
+        sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     }
-    const double sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-    *dst = accumulate ? (*dst + sum) : sum;
+    red[tid] = sum;
+    __syncthreads();
+    if (q0 == 0 && dst) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) t += red[q * SKM_RED_OUT + o];
+        *dst = accumulate ? (*dst + t) : t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2602,6 +2844,9 @@ struct Plan {
     // single-sweep kernel (7..16 component tiles, D <= 63)
     int fused, fused_nwv, fused_blocks, fused_fat, fat_blocks;
     size_t fused_lds;
+    // one-wave single-sweep kernel (1..4 component tiles): component tiles per wave, workgroups (= waves)
+    int solo, solo_nct, solo_blocks;
+    size_t solo_lds;
     // team kernel (C > 512 in multiples of 512): B workgroups per team, teams of one XCD share blockIdx % 8
     int team, team_B, team_per_xcd, team_wgs;
     size_t team_lds, off_xch, off_flags, off_err;
@@ -2612,6 +2857,14 @@ struct Plan {
 static size_t lds_bytes(int nct, int nw, const GmmGeom &g)
 {
     return ((size_t)nct * g.NCH * 256 + (size_t)nw * (32 * g.XS + 32)) * sizeof(float);
+}
+
+// frame tiles a wave accumulates in f32 registers between two folds into its f64 slab
+static int skm_flush_tiles()
+{
+    const char *e = getenv("SKM_FLUSH");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : SKM_FLUSH_TILES;
 }
 
 static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan *p)
@@ -2664,7 +2917,16 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
     const int wgs = ctx->cu_count > 0 ? ctx->cu_count : 256;
     p->n_fs1 = wgs / p->n_cb1 > 0 ? wgs / p->n_cb1 : 1;
     p->n_fs2 = wgs / p->n_cb2 > 0 ? wgs / p->n_cb2 : 1;
-    p->n_llk = 1024;
+    p->n_llk = 2048;
+    // one wave per workgroup holds all components (C <= 128); staging needs 32*D <= 32 floats * 64 lanes
+    {
+        const char *e = getenv("SKM_SOLO");
+        p->solo = (with_s && g.CT <= 4 && g.NJT <= 2 && 32 * g.D <= 2048 && (e ? atoi(e) != 0 : 1)) ? 1 : 0;
+        p->solo_nct = g.CT >= 3 ? 4 : g.CT;
+        p->solo_blocks = wgs * 4;
+        if (p->solo_blocks > p->n_llk) p->solo_blocks = p->n_llk;
+        p->solo_lds = ((size_t)2 * 32 * g.XS + 64) * sizeof(float);
+    }
     p->fused = (with_s && g.CT >= 7 && g.CT <= 16 && g.NJT <= 2 && !getenv("SKM_NO_FUSED")) ? 1 : 0;
     p->fused_nwv = (g.CT + 1) / 2;
     p->fused_blocks = wgs * (p->fused_nwv <= 4 ? 2 : 1);
@@ -2714,6 +2976,8 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         const size_t slfat = (size_t)p->fat_blocks * (g.CTpad / 4) * 128 * nf * 32 * sizeof(double);
         if (p->fused_fat && slfat > slf) slf = slfat;
         if (p->fused && slf > sl) sl = slf;
+        const size_t slsolo = (size_t)p->solo_blocks * p->solo_nct * 32 * nf * 32 * sizeof(double);
+        if (p->solo && slsolo > sl) sl = slsolo;
         const size_t slteam = (size_t)p->team_wgs * 4 * 128 * nf * 32 * sizeof(double);
         if (p->team && slteam > sl) sl = slteam;
         off += skm_align_up(sl, 256);
@@ -2856,6 +3120,50 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
     int rc;
     const float *wp = static_cast<const float *>(packed);
     const float *kc = wp + (size_t)p.g.CTpad * p.g.NCH * 256;
+    if (p.solo) {
+        // single sweep, all components in one wave (C <= 128)
+        FusedArgs f;
+        memset(&f, 0, sizeof(f));
+        f.X = X;
+        f.T = T;
+        f.g = p.tg;
+        f.wp = wp;
+        f.kc = kc;
+        f.slabs = reinterpret_cast<double *>(ws + p.off_slabs);
+        f.llk_part = reinterpret_cast<double *>(ws + p.off_llk);
+        f.flush_tiles = skm_flush_tiles();
+        const int nblk = p.solo_blocks, nf = 2 * p.g.NJT;
+        SKM_HIP(hipMemsetAsync(f.llk_part, 0, p.n_llk * sizeof(double), st));
+        {
+            SkmProfScope ps(ctx, "k_estep_solo", st);
+            const int geo = ((p.tg.NP & 1) ? 2 : 0) | (p.tg.tail ? 1 : 0);
+#define SKM_SOLO_LAUNCH(NCT_, NJT_, GEO_)                                                                      \
+    do {                                                                                                       \
+        if ((rc = set_lds(k_estep_solo<NCT_, NJT_, GEO_>, p.solo_lds))) return rc;                             \
+        hipLaunchKernelGGL((k_estep_solo<NCT_, NJT_, GEO_>), dim3(nblk), dim3(64), p.solo_lds, st, f);         \
+    } while (0)
+#define SKM_SOLO_GEO(NCT_)                                                                                     \
+    do {                                                                                                       \
+        if (p.g.NJT == 1) SKM_SOLO_LAUNCH(NCT_, 1, -1);      /* D < 32: geometry stays a run-time branch */    \
+        else if (geo == 0) SKM_SOLO_LAUNCH(NCT_, 2, 0);                                                        \
+        else if (geo == 1) SKM_SOLO_LAUNCH(NCT_, 2, 1);                                                        \
+        else if (geo == 2) SKM_SOLO_LAUNCH(NCT_, 2, 2);                                                        \
+        else SKM_SOLO_LAUNCH(NCT_, 2, 3);                                                                      \
+    } while (0)
+            if (p.solo_nct == 1) SKM_SOLO_GEO(1);
+            else if (p.solo_nct == 2) SKM_SOLO_GEO(2);
+            else SKM_SOLO_GEO(4);
+#undef SKM_SOLO_GEO
+#undef SKM_SOLO_LAUNCH
+        }
+        SKM_HIP(hipGetLastError());
+        const long n_out = (long)C * nf * 32;
+        SkmProfScope ps(ctx, "k_reduce_slabs", st);
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + SKM_RED_OUT - 1) / SKM_RED_OUT)), dim3(256), 0, st, f.slabs, 1, nblk,
+                           1, p.solo_nct, p.g.NJT, nf, C, D, out, accumulate, f.llk_part, p.n_llk);
+        SKM_HIP(hipGetLastError());
+        return SKM_OK;
+    }
     if (p.fused) {
         // single sweep: all components in one workgroup (C <= 512)
         FusedArgs f;
@@ -2873,9 +3181,11 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
             const char *e = getenv("SKM_STAGGER");
             f.stagger = e ? atoi(e) : 1;
         }
+        f.flush_tiles = skm_flush_tiles();
         const bool fat = p.fused_fat;
         const int nwv = fat ? p.g.CTpad / 4 : p.fused_nwv, nblk = fat ? p.fat_blocks : p.fused_blocks, nf = 2 * p.g.NJT;
-        SKM_HIP(hipMemsetAsync(f.slabs, 0, (size_t)nblk * nwv * (fat ? 128 : 64) * nf * 32 * sizeof(double), st));
+        // the fat kernel's first flush writes its slab; the older fused kernel adds to a cleared one
+        if (!fat) SKM_HIP(hipMemsetAsync(f.slabs, 0, (size_t)nblk * nwv * 64 * nf * 32 * sizeof(double), st));
         SKM_HIP(hipMemsetAsync(f.llk_part, 0, p.n_llk * sizeof(double), st));
         {
             SkmProfScope ps(ctx, fat ? "k_estep_fat" : "k_estep_fused", st);
@@ -2914,7 +3224,7 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
         SKM_HIP(hipGetLastError());
         const long n_out = (long)C * nf * 32;
         SkmProfScope ps(ctx, "k_reduce_slabs", st);
-        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, f.slabs, nwv, nblk,
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + SKM_RED_OUT - 1) / SKM_RED_OUT)), dim3(256), 0, st, f.slabs, nwv, nblk,
                            1, fat ? 4 : 2, p.g.NJT, nf, C, D, out, accumulate, f.llk_part, p.n_llk);
         SKM_HIP(hipGetLastError());
         return SKM_OK;
@@ -2980,7 +3290,7 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
         if (le == hipSuccess) {
             const long n_out = (long)C * nf * 32;
             SkmProfScope ps(ctx, "k_reduce_slabs", st);
-            hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, t.slabs,
+            hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + SKM_RED_OUT - 1) / SKM_RED_OUT)), dim3(256), 0, st, t.slabs,
                                4 * p.team_B, 8 * p.team_per_xcd, 1, 4, p.g.NJT, nf, C, D, out, accumulate, t.llk_part,
                                p.n_llk, t.err);
             SKM_HIP(hipGetLastError());
@@ -3012,7 +3322,7 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
     const long n_out = (long)C * p.nf2 * 32;
     {
         SkmProfScope ps(ctx, "k_reduce_slabs", st);
-        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, a.slabs,
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + SKM_RED_OUT - 1) / SKM_RED_OUT)), dim3(256), 0, st, a.slabs,
                            p.n_cb2, p.n_fs2, p.nw2, p.nct2, p.g.NJT, p.nf2, C, D, out, accumulate,
                            reinterpret_cast<const double *>(ws + p.off_llk), p.n_llk);
     }
@@ -3050,7 +3360,7 @@ extern "C" int skm_gmm_estep_noalloc(void *ctx_, const float *X, long T, int C, 
     Plan p;
     int rc = make_plan(ctx, 0, C, D, true, &p);          // layout without the T-sized two-sweep regions
     if (rc) return rc;
-    const bool single = p.fused || (p.team && p.team_B >= 2);
+    const bool single = p.solo || p.fused || (p.team && p.team_B >= 2);
     if (!single && (rc = make_plan(ctx, T, C, D, true, &p))) return rc;
     if (p.total > SKM_SCRATCH_BYTES) {
         skm_set_error("skm_gmm_estep_noalloc: T=%ld C=%d D=%d needs %zu bytes of scratch, the built-in array holds %zu "

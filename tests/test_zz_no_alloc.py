@@ -24,7 +24,10 @@ def _rel(a, b):
 @pytest.mark.parametrize("C,D,T1,T2", [(512, 60, 50000, 6001),       # single-sweep one-wave-per-SIMD kernel
                                        (2048, 60, 40000, 3000),      # team kernel (cooperative launch)
                                        (256, 20, 9000, 500),         # fused two-wave kernel
-                                       (64, 13, 3000, 777)])         # two sweeps: per-frame partials in the scratch
+                                       (128, 60, 20000, 999),        # one-wave kernel, four component tiles
+                                       (64, 13, 3000, 777),          # one-wave kernel, two tiles, scalar staging
+                                       (20, 24, 5000, 31),           # one-wave kernel, one tile
+                                       (160, 13, 3000, 777)])        # two sweeps: per-frame partials in the scratch
 def test_noalloc_equals_workspace_entry_point(eng, C, D, T1, T2):
     torch = eng.torch
     gmm = orc.random_gmm(C, D, seed=C + D)
@@ -56,12 +59,13 @@ def test_noalloc_rejects_what_does_not_fit(eng):
     import sidekit_amd
     lib = eng.lib
     assert lib.skm_gmm_estep_noalloc_max_bytes() == 144 << 20
-    C, D = 64, 13
+    C, D, T = 160, 13, 10_000_000                                    # five component tiles: no single-sweep kernel
     gmm = orc.random_gmm(C, D, seed=1)
     packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
-    X = eng.upload_frames(orc.synth_frames(64, dim=D, seed=2))
+    # X really holds T frames: a library that failed to refuse the call would run it, not fault the card
+    X = eng.torch.zeros((T, D), dtype=eng.torch.float32, device=eng.device)
     out = eng.torch.zeros(2 * C * D + C + 1, dtype=eng.torch.float64, device=eng.device)
-    rc = lib.skm_gmm_estep_noalloc(eng.ctx, ctypes.c_void_p(X.data_ptr()), 50_000_000, C, D,
+    rc = lib.skm_gmm_estep_noalloc(eng.ctx, ctypes.c_void_p(X.data_ptr()), T, C, D,
                                    ctypes.c_void_p(packed.packed.data_ptr()), ctypes.c_void_p(out.data_ptr()), 0, None)
     assert rc == -3
     assert b"scratch" in lib.skm_last_error()
