@@ -1286,7 +1286,9 @@ __device__ __forceinline__ void gemm_logits_fat(f32x16 (&lg)[NCT], WSet<NCT> &wa
     }
 }
 
-template <int NJT, int NCT, bool WITH_S = true>
+// VACC: the accumulators live in VGPRs (a kernel that uses no AGPR at all gets the whole 256-register budget of a
+// two-waves-per-SIMD launch as VGPRs; with any AGPR use hipcc splits that budget 128 / 128)
+template <int NJT, int NCT, bool WITH_S = true, bool VACC = false>
 __device__ __forceinline__ void gemm_stats_agpr(f32x16 (&acc)[NCT][NJT * (WITH_S ? 2 : 1)], const f32x16 (&lg)[NCT],
                                                 const float *xcol, int XS)
 {
@@ -1309,13 +1311,23 @@ __device__ __forceinline__ void gemm_stats_agpr(f32x16 (&acc)[NCT][NJT * (WITH_S
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) mfma_agpr(acc[ct][jt], lg[ct][r], b[jt]);
+            for (int ct = 0; ct < NCT; ++ct) {
+                if (VACC)
+                    mfma_vgpr(acc[ct][jt], lg[ct][r], b[jt]);
+                else
+                    mfma_agpr(acc[ct][jt], lg[ct][r], b[jt]);
+            }
         if (WITH_S) {
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
-                    if (ct == 0)
+                    if (VACC) {
+                        if (ct == 0)
+                            mfma_vgpr_after_valu(acc[ct][NJT * (WITH_S ? 1 : 0) + jt], lg[ct][r], b2[jt]);
+                        else
+                            mfma_vgpr(acc[ct][NJT * (WITH_S ? 1 : 0) + jt], lg[ct][r], b2[jt]);
+                    } else if (ct == 0)
                         mfma_agpr_after_valu(acc[ct][NJT * (WITH_S ? 1 : 0) + jt], lg[ct][r], b2[jt]);
                     else
                         mfma_agpr(acc[ct][NJT * (WITH_S ? 1 : 0) + jt], lg[ct][r], b2[jt]);
@@ -1325,7 +1337,7 @@ __device__ __forceinline__ void gemm_stats_agpr(f32x16 (&acc)[NCT][NJT * (WITH_S
 }
 
 // STORE: the first flush of a wave writes its slab instead of adding to it (no memset, no read)
-template <int NCT, int NF, bool STORE = false>
+template <int NCT, int NF, bool STORE = false, bool VACC = false>
 __device__ __forceinline__ void flush_slab_agpr(f32x16 (&acc)[NCT][NF], double *slab_lane)
 {
     constexpr int NFW = NF * 32;
@@ -1333,7 +1345,10 @@ __device__ __forceinline__ void flush_slab_agpr(f32x16 (&acc)[NCT][NF], double *
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int jf = 0; jf < NF; ++jf) {
-            agpr_settle(acc[ct][jf]);
+            if (VACC)
+                vgpr_settle(acc[ct][jf]);
+            else
+                agpr_settle(acc[ct][jf]);
             double *p = slab_lane + ct * 32 * NFW + jf * 32;
             const f32x16 v = acc[ct][jf];
             double old[16];
@@ -1602,9 +1617,10 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
 // the other.
 // ------------------------------------------------------------------------------------------------
 template <int NCT, int NJT, int GEO>
-__global__ __launch_bounds__(64, 1) void k_estep_solo(FusedArgs a)
+__global__ __launch_bounds__(64, NCT == 1 ? 2 : 1) void k_estep_solo(FusedArgs a)
 {
-    constexpr int NF = 2 * NJT, NFW = NF * 32, PRE = 32;
+    constexpr int NF = 2 * NJT, NFW = NF * 32;
+    constexpr bool VACC = NCT == 1;     // two waves per SIMD: 256 VGPRs, no AGPR
     extern __shared__ __align__(16) float smem[];
     const int lane = threadIdx.x;
     const int h = lane >> 5, c = lane & 31;
@@ -1642,72 +1658,31 @@ __global__ __launch_bounds__(64, 1) void k_estep_solo(FusedArgs a)
     double *slab_lane = a.slabs + (long)blockIdx.x * (long)(NCT * 32 * NFW) + (4 * h) * NFW + c;
     double llk_lane = 0.0;
 
-    // staging of the contiguous 32*D span of a tile: 32 floats per lane (host: 32*D <= 2048)
-    constexpr int NST = PRE / 4;
-    float pre[PRE];
-    int st_row[NST], st_dst[NST];
+    // Frame tiles go from HBM straight into LDS (buffer_load ... lds, one row of D floats per instruction, lanes
+    // < D): no staging registers, no vector ALU.  The row's descriptor is rebuilt by the scalar unit; rows past
+    // the end of X get an empty extent, so their lanes write zeros.  hipcc does not order these loads against
+    // later LDS reads, hence the explicit vmcnt(0) at the top of every tile.
+    const int row_bytes = g.D * 4;
+    auto dma_tile = [&](long tile, float *slot) __attribute__((always_inline)) {
+        const long t0 = tile << 5;
+        const long left = a.T - t0;
+        const char *base = reinterpret_cast<const char *>(a.X + t0 * (long)g.D);
+        if (lane < g.D) {
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
-        const int e = lane + i * 64;
-        const int n4 = g.D >> 2;
-        const int row = g.vec4 ? e / n4 : 0;
-        st_row[i] = (g.vec4 && e < 32 * n4) ? row : 1 << 20;
-        st_dst[i] = row * g.XS + 4 * (e - row * n4);
-    }
-    auto load_pre = [&](long t0, int nvalid) __attribute__((always_inline)) {
-        if (g.vec4) {
-            const f32x4 *X4 = reinterpret_cast<const f32x4 *>(a.X + t0 * (long)g.D);
-#pragma unroll
-            for (int i = 0; i < NST; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (st_row[i] < nvalid) v = X4[lane + i * 64];
-                pre[4 * i + 0] = v[0];
-                pre[4 * i + 1] = v[1];
-                pre[4 * i + 2] = v[2];
-                pre[4 * i + 3] = v[3];
-            }
-        } else {
-            const float *Xs = a.X + t0 * (long)g.D;
-            const int n_el = 32 * g.D;
-#pragma unroll
-            for (int i = 0; i < PRE; ++i) {
-                const int e = lane + i * 64;
-                pre[i] = (e < n_el && e / g.D < nvalid) ? Xs[e] : 0.f;
-            }
-        }
-    };
-    auto store_pre = [&](float *dst) __attribute__((always_inline)) {
-        if (g.vec4) {
-#pragma unroll
-            for (int i = 0; i < NST; ++i) {
-                if (st_row[i] < 32) {
-                    f32x4 v = {pre[4 * i], pre[4 * i + 1], pre[4 * i + 2], pre[4 * i + 3]};
-                    *reinterpret_cast<f32x4 *>(dst + st_dst[i]) = v;
-                }
-            }
-        } else {
-            const int n_el = 32 * g.D;
-#pragma unroll
-            for (int i = 0; i < PRE; ++i) {
-                const int e = lane + i * 64;
-                if (e < n_el) {
-                    const int row = e / g.D;
-                    dst[row * g.XS + (e - row * g.D)] = pre[i];
-                }
+            for (int r = 0; r < 32; ++r) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char *>(base + (long)r * row_bytes), 0, r < left ? row_bytes : 0, 0x00027000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(slot + r * g.XS),
+                                                         4, lane * 4, 0, 0, 0);
             }
         }
     };
     auto valid_in = [&](long t0) __attribute__((always_inline)) { return (int)((a.T - t0) < 32 ? (a.T - t0) : 32); };
 
-    if (ta < tb) {
-        const long t0 = ta << 5;
-        load_pre(t0, valid_in(t0));
-        store_pre(xs);
-        if (ta + 1 < tb) load_pre(t0 + 32, valid_in(t0 + 32));
-    }
+    wave_lds_fence();
+    if (ta < tb) dma_tile(ta, xs);
     WSet<NCT> wa;
     wset_load<NCT>(wa, Wg4, g.NG, g.NP, 0);
-    wave_lds_fence();
 
     const int frame = acc_row((c >> 1) & 15, h);
     bool first = true;
@@ -1718,6 +1693,7 @@ __global__ __launch_bounds__(64, 1) void k_estep_solo(FusedArgs a)
     for (long tile = base; tile < end; ++tile) {
         const int nvalid = valid_in(tile << 5);
         const float *xt = xs + cur * tile_floats;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this tile's frames are in LDS
 
         f32x16 lg[NCT];
 #pragma unroll
@@ -1764,8 +1740,6 @@ __global__ __launch_bounds__(64, 1) void k_estep_solo(FusedArgs a)
             ls[32 + frame] = valid ? __builtin_amdgcn_rcpf(sm[0]) : 0.f;
             if (valid) llk_lane += (double)(m[0] + __builtin_amdgcn_logf(sm[0]));
         }
-        // next tile goes to the other slot: its last reader was the previous tile's statistics GEMM
-        if (tile + 1 < tb) store_pre(xs + (cur ^ 1) * tile_floats);
         wave_lds_fence();
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
@@ -1778,21 +1752,22 @@ __global__ __launch_bounds__(64, 1) void k_estep_solo(FusedArgs a)
                 lg[ct][4 * q4 + 3] *= f4[3];
             }
         }
-        // frames of tile+2 are requested in front of the statistics GEMM, which has no vector-memory wait
-        if (tile + 2 < tb) load_pre((tile + 2) << 5, valid_in((tile + 2) << 5));
+        // the next tile is requested in front of the statistics GEMM, which has no vector-memory wait; it goes to the
+        // other slot, whose last reader was the previous tile's statistics GEMM
+        if (tile + 1 < tb) dma_tile(tile + 1, xs + (cur ^ 1) * tile_floats);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
-        gemm_stats_agpr<NJT, NCT>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
+        gemm_stats_agpr<NJT, NCT, true, VACC>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
         wave_lds_fence();
         cur ^= 1;
     }
     if (first)
-        flush_slab_agpr<NCT, NF, true>(acc, slab_lane);
+        flush_slab_agpr<NCT, NF, true, VACC>(acc, slab_lane);
     else
-        flush_slab_agpr<NCT, NF, false>(acc, slab_lane);
+        flush_slab_agpr<NCT, NF, false, VACC>(acc, slab_lane);
     first = false;
     }
-    if (first) flush_slab_agpr<NCT, NF, true>(acc, slab_lane);   // empty range: the slab must still read as zero
+    if (first) flush_slab_agpr<NCT, NF, true, VACC>(acc, slab_lane);   // empty range: the slab must still read as zero
 #pragma unroll
     for (int msk = 1; msk < 64; msk <<= 1) llk_lane += __shfl_xor(llk_lane, msk);
     if (lane == 0) a.llk_part[blockIdx.x] = llk_lane * 0.6931471805599453094;
@@ -2923,7 +2898,7 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         const char *e = getenv("SKM_SOLO");
         p->solo = (with_s && g.CT <= 4 && g.NJT <= 2 && 32 * g.D <= 2048 && (e ? atoi(e) != 0 : 1)) ? 1 : 0;
         p->solo_nct = g.CT >= 3 ? 4 : g.CT;
-        p->solo_blocks = wgs * 4;
+        p->solo_blocks = wgs * 4 * (p->solo_nct == 1 ? 2 : 1);
         if (p->solo_blocks > p->n_llk) p->solo_blocks = p->n_llk;
         p->solo_lds = ((size_t)2 * 32 * g.XS + 64) * sizeof(float);
     }
@@ -3144,8 +3119,14 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
     } while (0)
 #define SKM_SOLO_GEO(NCT_)                                                                                     \
     do {                                                                                                       \
-        if (p.g.NJT == 1) SKM_SOLO_LAUNCH(NCT_, 1, -1);      /* D < 32: geometry stays a run-time branch */    \
-        else if (geo == 0) SKM_SOLO_LAUNCH(NCT_, 2, 0);                                                        \
+        /* the geometry is a template argument for every D: the run-time form of the logits ending (branches that  \
+           merge behind asm MFMAs) gave wrong logits in this kernel for an even pair count with a tail group */    \
+        if (p.g.NJT == 1) {                                                                                    \
+            if (geo == 0) SKM_SOLO_LAUNCH(NCT_, 1, 0);                                                         \
+            else if (geo == 1) SKM_SOLO_LAUNCH(NCT_, 1, 1);                                                    \
+            else if (geo == 2) SKM_SOLO_LAUNCH(NCT_, 1, 2);                                                    \
+            else SKM_SOLO_LAUNCH(NCT_, 1, 3);                                                                  \
+        } else if (geo == 0) SKM_SOLO_LAUNCH(NCT_, 2, 0);                                                      \
         else if (geo == 1) SKM_SOLO_LAUNCH(NCT_, 2, 1);                                                        \
         else if (geo == 2) SKM_SOLO_LAUNCH(NCT_, 2, 2);                                                        \
         else SKM_SOLO_LAUNCH(NCT_, 2, 3);                                                                      \

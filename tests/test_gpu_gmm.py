@@ -75,6 +75,10 @@ def test_estep_vs_reference_golden(eng, tag):
 
 @pytest.mark.parametrize("C,D,T", [(1, 60, 1000), (2, 60, 33), (33, 60, 4097), (512, 60, 20000), (96, 20, 5000),
                                    (64, 132, 3000), (130, 7, 2049), (256, 39, 7001), (2048, 60, 6000),
+                                   # one-wave kernel (C <= 128): every ending of the logits GEMM (pair count even / odd, with /
+                                   # without a tail group) at one, two and four component tiles; several tiles per wave
+                                   (64, 20, 320), (64, 4, 320), (128, 36, 5000), (20, 36, 320), (100, 28, 777), (17, 16, 100),
+                                   (128, 60, 300000), (32, 60, 200000), (48, 13, 150000),
                                    # team kernel (C = 1024 / 2048 / 4096): ragged last tile, fewer tiles than teams, one frame
                                    (1024, 60, 9999), (2048, 20, 12345), (2048, 60, 95), (1024, 64, 1), (4096, 60, 4100)])
 def test_estep_vs_oracle_shapes(eng, C, D, T):
