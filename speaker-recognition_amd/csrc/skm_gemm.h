@@ -2,11 +2,14 @@
 //
 //   C[z] = alpha * op(A[z]) * op(B[z]) + beta * C[z]        (row-major, leading dimensions in elements)
 //
-// TI = float  -> v_mfma_f32_32x32x2_f32, block tile 128 x 128, BK 16
+// TI = float  -> v_mfma_f32_32x32x2_f32, block tile 128 x 128, BK 32 (16 with ACC64)
 // TI = double -> v_mfma_f64_16x16x4_f64, block tile  64 x  64, BK 16
 // TO is the storage type of C (float or double).  With ACC64 (TI = float only) the f32 MFMA
-// accumulators are folded into float64 registers every 256 k-steps so that long reductions
-// (K = C*D = 122 880 for the TV first-order projection) keep float64-grade sums.
+// accumulators are folded into float64 registers every 256 k-steps; the TV hot path no longer uses it
+// (long reductions are cut into K = 2048 products accumulated in a float64 C with beta = 1).
+// Kernel (skm_gemm.hip, device helpers in skm_gemm_dev.h): 8 waves per workgroup, waves 0-3 read LDS and issue
+// MFMAs only, waves 4-7 stage tiles (buffer loads with hardware range checks -> registers -> ds_write_b128);
+// per-operand LDS layout chosen by the operand's contiguous dimension (AKF / BKF template flags).
 //
 // Extras used by the blocked Cholesky / TV E-step:
 //   tile_mask  0: all of C, 1: only the 32 x 32 blocks of C on or above the block diagonal (column block >=
