@@ -632,6 +632,8 @@ def main():
         eng.profile_read()
         eng.profile(False)
         flop_train, flop_iv = 9.18e8, 4.5e8          # algorithmic flop per session
+        chain_dtype = "f64" if os.environ.get("SKM_TV_CHAIN", "").lower() == "f64" else "f32"
+        chain_peak = PEAK_F64_MFMA_TFLOPS if chain_dtype == "f64" else PEAK_F32_MFMA_TFLOPS
         Sall = args.tv_sessions
         # float64 chain of the E-step (Cholesky, triangular inverse, X X'): algorithmic R^3 flop per session
         t_f64 = sum(v[1] for k, v in prof_tv.items()
@@ -648,8 +650,12 @@ def main():
             "ivectors_with_uncertainty_per_s": Sall / dt_ivu,
             "extract_algorithmic_tflops": flop_iv * Sall / dt_iv / 1e12,
             "extract_frac_of_f32_mfma_peak": flop_iv * Sall / dt_iv / 1e12 / PEAK_F32_MFMA_TFLOPS / world,
-            "f64_chain": {"ms": round(t_f64, 3), "algorithmic_tflops": float(R) ** 3 * St / (t_f64 * 1e-3) / 1e12 if t_f64 else None,
-                          "frac_of_f64_mfma_peak": float(R) ** 3 * St / (t_f64 * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS if t_f64 else None},
+            # per-session chain (Cholesky, triangular inverse, X X'): float32 storage and MFMAs by default, float64 with
+            # SKM_TV_CHAIN=f64; R^3 algorithmic flop per session, priced against the peak of the type it runs in
+            "chain": {"dtype": chain_dtype, "ms": round(t_f64, 3),
+                      "algorithmic_tflops": float(R) ** 3 * St / (t_f64 * 1e-3) / 1e12 if t_f64 else None,
+                      "frac_of_mfma_peak": float(R) ** 3 * St / (t_f64 * 1e-3) / 1e12 / chain_peak if t_f64 else None,
+                      "bound": "hbm (64-wide panel products: 8 flop/B in float64, 16 in float32; tools/time_chain_gemm.py)"},
             "train_kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof_tv.items())},
             "extract_kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof_iv.items())},
             "note": "M-step cost (R x R inverses of the rank's C/N components) is independent of the session count; it is "

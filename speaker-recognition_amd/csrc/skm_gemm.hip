@@ -15,10 +15,10 @@
 // cycles from that SIMD's MFMA stream whichever wave issues it -- see the staging loop.)  One raw s_barrier per k-tile
 // joins the two roles; the staging waves wait only for their LDS stores in front of it (never vmcnt(0): the loads of
 // later tiles stay in flight across it).
-template <typename TI, typename TO, bool ACC64, bool GUARD, bool AKF, bool BKF>
+template <typename TI, typename TO, bool ACC64, bool GUARD, bool AKF, bool BKF, bool SM = false>
 __global__ __launch_bounds__(512, (sizeof(TI) == 4 && ACC64) ? 1 : 2) void k_gemm(GemmArgs g)
 {
-    typedef Mf<TI> M;
+    typedef typename MfSel<TI, SM>::type M;     // SM: float32 on 16 x 16 x 4 MFMAs, 64 x 64 tiles
     constexpr int TM = M::TM, KS = M::KS, NR = M::NR;
     constexpr int BM = 4 * TM, BN = 4 * TM;
     constexpr int BK = (sizeof(TI) == 4 && !ACC64) ? 32 : 16;
@@ -317,6 +317,7 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
     SKM_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0 && batch > 0, "gemm(%s): bad shape M=%d N=%d K=%d batch=%d", tag,
                 g.M, g.N, g.K, batch);
     const int tile = (kind == SKM_GEMM_F32_F32 || kind == SKM_GEMM_F32_F64ACC || kind == SKM_GEMM_F32_F64OUT) ? 128 : 64;
+    SKM_REQUIRE(kind != SKM_GEMM_F32S_F32 || !g.colmap, "gemm(%s): the small-tile float32 kernel has no column map", tag);
     const int ncols = g.tri_n > 0 ? g.tri_n : g.N;
     dim3 grid((ncols + tile - 1) / tile, (g.M + tile - 1) / tile, batch);
     SKM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm(%s): grid too large", tag);
@@ -360,6 +361,13 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
         else if (!g.transA && g.transB) hipLaunchKernelGGL((k_gemm<TI_, TO_, ACC_, G_, true, true>), grid, dim3(512), 0, st, gv);   \
         else hipLaunchKernelGGL((k_gemm<TI_, TO_, ACC_, G_, false, true>), grid, dim3(512), 0, st, gv);              \
     } while (0)
+#define SKM_GEMM_LS(G_)                                                                                             \
+    do {                                                                                                             \
+        if (!g.transA && !g.transB) hipLaunchKernelGGL((k_gemm<float, float, false, G_, true, false, true>), grid, dim3(512), 0, st, gv);      \
+        else if (g.transA && !g.transB) hipLaunchKernelGGL((k_gemm<float, float, false, G_, false, false, true>), grid, dim3(512), 0, st, gv); \
+        else if (!g.transA && g.transB) hipLaunchKernelGGL((k_gemm<float, float, false, G_, true, true, true>), grid, dim3(512), 0, st, gv);   \
+        else hipLaunchKernelGGL((k_gemm<float, float, false, G_, false, true, true>), grid, dim3(512), 0, st, gv);   \
+    } while (0)
 #define SKM_GEMM_GO(TI_, TO_, ACC_)                    \
     do {                                               \
         if (guard) SKM_GEMM_L(TI_, TO_, ACC_, true);   \
@@ -371,10 +379,15 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
     case SKM_GEMM_F32_F64OUT: SKM_GEMM_GO(float, double, false); break;
     case SKM_GEMM_F64_F64: SKM_GEMM_GO(double, double, false); break;
     case SKM_GEMM_F64_F32OUT: SKM_GEMM_GO(double, float, false); break;
+    case SKM_GEMM_F32S_F32:
+        if (guard) SKM_GEMM_LS(true);
+        else SKM_GEMM_LS(false);
+        break;
     default: skm_set_error("gemm(%s): unknown kind %d", tag, kind); return SKM_ERR_ARG;
     }
 #undef SKM_GEMM_GO
 #undef SKM_GEMM_L
+#undef SKM_GEMM_LS
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }

@@ -25,6 +25,27 @@ struct Mf<double> {
     static __device__ __forceinline__ int row(int r, int lane) { return (lane >> 4) + 4 * r; }
 };
 
+// float32 on 16 x 16 x 4 MFMAs: 64 x 64 workgroup tiles for batches of small matrices (the per-session Cholesky
+// chain of the TV E-step, whose panels are 64 wide); same flop rate per SIMD as the 32 x 32 x 2 instruction.
+struct MfF32Small {
+    static constexpr int TM = 16, KS = 4, NR = 4;
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int r, int lane) { return 4 * (lane >> 4) + r; }
+};
+
+template <typename T, bool SMALL>
+struct MfSel {
+    typedef Mf<T> type;
+};
+template <>
+struct MfSel<float, true> {
+    typedef MfF32Small type;
+};
+
 // Operand tile loader: BROWS x BK logical tile (row = m or n, col = k), 256 threads, 16-byte vectors along
 // the contiguous dimension of the stored matrix when `vec` (alignment checked on the host).
 //   KFAST: the stored matrix is contiguous along k (A not transposed / B transposed), else along the row.

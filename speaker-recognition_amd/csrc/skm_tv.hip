@@ -22,7 +22,7 @@
 // never read except where the buffer was zero-filled.
 #include "skm_gemm.h"
 
-#define TV_BLK 32
+#define TV_BLK 4
 
 // row stride of naug = [N | 1 | 0-pad]: C+1 rounded up to 4 floats so that rows stay 16-byte aligned
 static inline int tv_ldn(int C) { return (C + 1 + 3) / 4 * 4; }
@@ -59,8 +59,11 @@ __global__ __launch_bounds__(256) void k_tv_whiten(const TS *__restrict__ stat0,
     }
 }
 
-// Column map of the flattened upper-block view of an R x R matrix: for row z (block b = z / 32) the logical
-// columns start(z) .. start(z) + R - 32 b - 1 map to element offsets z*R + 32 b + j.
+// Column map of the flattened "upper part" view of an R x R matrix: row z keeps the columns from the start of its
+// 4-wide block (TV_BLK: 16-byte vectors stay aligned; 80 800 of 160 000 entries at R = 400, the exact triangle has
+// 80 200): for row z (block b = z / TV_BLK) the logical columns start(z) .. start(z) + R - TV_BLK b - 1 map to element
+// offsets z*R + TV_BLK b + j.  Nothing downstream reads below the diagonal: the diagonal-block kernel loads r <= c
+// only, the panel products read rows above their block, e_hh / A are consumed as upper triangles.
 #define TV_CS_SPLIT 16   // session ranges of the e_hh column sums
 #define TV_AUX_CHUNK 2048 // k per float32 accumulation run of the aux product (float64 across runs)
 static inline long tv_tri_cols(int R)
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void k_tri_map(int *__restrict__ map, int R)
 {
     const int z = blockIdx.x;
     const int b = z / TV_BLK, col0 = b * TV_BLK;
-    // start(z) = sum_{b' < b} 32 (R - 32 b') + (z - 32 b)(R - 32 b)
+    // start(z) = sum_{b' < b} BLK (R - BLK b') + (z - BLK b)(R - BLK b)
     long start = (long)TV_BLK * ((long)b * R - (long)TV_BLK * b * (b - 1) / 2) + (long)(z - col0) * (R - col0);
     for (int j = threadIdx.x; j < R - col0; j += blockDim.x) map[start + j] = z * R + col0 + j;
 }
@@ -116,29 +119,38 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane)
     hi = __builtin_amdgcn_readlane(hi, src_lane);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float lane_bcast(float v, int src_lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+__device__ __forceinline__ double tv_sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ float tv_sqrt(float v) { return __fsqrt_rn(v); }
 
-__global__ __launch_bounds__(256) void k_chol_diag(double *__restrict__ Mb, long stride, int ld, int n, int add_identity,
+// T = double: the M-step (one matrix per component) and, with SKM_TV_CHAIN=f64, the per-session chain;
+// T = float: the per-session chain (default, see tv_chain_f64()).
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_diag(T *__restrict__ Mb, long stride, int ld, int n, int add_identity,
                                                    int nb)
 {
     const int lane = threadIdx.x & 63;
     const long mi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (mi >= nb) return;                       // wave-uniform
-    double *M = Mb + mi * stride;
-    double col[CH_BLK];
+    T *M = Mb + mi * stride;
+    T col[CH_BLK];
 #pragma unroll
     for (int r = 0; r < CH_BLK; ++r) {
-        double v = 0.0;
+        T v = 0;
         if (r < n && lane < n && r <= lane) v = M[(long)r * ld + lane];
-        if (add_identity && r == lane && r < n) v += 1.0;
+        if (add_identity && r == lane && r < n) v += (T)1;
         col[r] = v;
     }
-    double dinv_own = 0.0;                      // 1 / U[c][c] of this lane's column
+    T dinv_own = 0;                             // 1 / U[c][c] of this lane's column
 #pragma unroll
     for (int j = 0; j < CH_BLK; ++j) {
         if (j < n) {                            // uniform
-            const double d = sqrt(lane_bcast(col[j], j));
-            const double u = col[j] / d;
-            dinv_own = (lane == j) ? 1.0 / d : dinv_own;
+            const T d = tv_sqrt(lane_bcast(col[j], j));
+            const T u = col[j] / d;
+            dinv_own = (lane == j) ? (T)1 / d : dinv_own;
             col[j] = (lane > j) ? u : col[j];   // row j scaled right of the pivot; the pivot itself stays
 #pragma unroll
             for (int r = j + 1; r < CH_BLK; ++r) {
@@ -148,16 +160,16 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *__restrict__ Mb, long
         }
     }
 #pragma unroll
-    for (int r = 0; r < CH_BLK; ++r) col[r] = (r > lane) ? 0.0 : col[r];
+    for (int r = 0; r < CH_BLK; ++r) col[r] = (r > lane) ? (T)0 : col[r];
     // W = U^-1 by rows, bottom-up: W[i][c] = -(sum_{l=i+1..c} U[i][l] W[l][c]) / U[i][i], W[c][c] = 1 / U[c][c]
 #pragma unroll
     for (int i = CH_BLK - 1; i >= 0; --i) {
         if (i < n) {                            // uniform
-            double acc = 0.0;
+            T acc = 0;
 #pragma unroll
             for (int l = i + 1; l < CH_BLK; ++l) acc += lane_bcast(col[i], l) * col[l];   // W[l][c] = 0 for l > c
-            const double w = -acc * lane_bcast(dinv_own, i);
-            col[i] = (lane > i) ? w : ((lane == i) ? dinv_own : 0.0);
+            const T w = -acc * lane_bcast(dinv_own, i);
+            col[i] = (lane > i) ? w : ((lane == i) ? dinv_own : (T)0);
         }
     }
     if (lane < n) {
@@ -170,14 +182,15 @@ __global__ __launch_bounds__(256) void k_chol_diag(double *__restrict__ Mb, long
 // ------------------------------------------------------------------------------------------------
 // per session: e_h = L^-1 aux (L^-1 symmetric, upper part valid), e_hh = L^-1 + e_h e_h'
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tv_finish(const double *__restrict__ Linv, int R, const double *__restrict__ aux,
+template <typename T>
+__global__ __launch_bounds__(256) void k_tv_finish(const T *__restrict__ Linv, int R, const double *__restrict__ aux,
                                                    double *__restrict__ e_h, float *__restrict__ e_h32,
                                                    double *__restrict__ iv_sigma, float *__restrict__ E)
 {
     extern __shared__ double sh[];  // aux[R], y[R]
     double *ax = sh, *y = sh + R;
     const long b = blockIdx.x;
-    const double *Li = Linv + b * (long)R * R;
+    const T *Li = Linv + b * (long)R * R;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int i = t; i < R; i += 256) {
         ax[i] = aux[b * R + i];
@@ -187,14 +200,14 @@ __global__ __launch_bounds__(256) void k_tv_finish(const double *__restrict__ Li
     // y[j] = sum_{i<=j} U[i][j] ax[i]   (column sweep, coalesced along j)
     for (int j = t; j < R; j += 256) {
         double s = 0.0;
-        for (int i = 0; i <= j; ++i) s += Li[(long)i * R + j] * ax[i];
+        for (int i = 0; i <= j; ++i) s += (double)Li[(long)i * R + j] * ax[i];
         y[j] = s;
     }
     __syncthreads();
     // y[i] += sum_{j>i} U[i][j] ax[j]   (row reduce, one wave per row)
     for (int i = wave; i < R; i += 4) {
         double s = 0.0;
-        for (int j = i + 1 + lane; j < R; j += 64) s += Li[(long)i * R + j] * ax[j];
+        for (int j = i + 1 + lane; j < R; j += 64) s += (double)Li[(long)i * R + j] * ax[j];
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
         if (lane == 0) y[i] += s;
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(256) void k_tv_finish(const double *__restrict__ Li
         const double v = y[i];
         e_h[b * R + i] = v;
         if (e_h32) e_h32[b * R + i] = (float)v;
-        if (iv_sigma) iv_sigma[b * R + i] = Li[(long)i * R + i] + v * v;
+        if (iv_sigma) iv_sigma[b * R + i] = (double)Li[(long)i * R + i] + v * v;
     }
     if (E) {
         float *Eb = E + b * (long)R * R;
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(256) void k_tv_finish(const double *__restrict__ Li
             const double yi = y[i];
             for (int j = col0 + lane; j < R; j += 64) {
                 // inside the diagonal block the strictly-lower entries mirror the upper ones
-                const double l = (j >= i) ? Li[(long)i * R + j] : Li[(long)j * R + i];
+                const double l = (double)((j >= i) ? Li[(long)i * R + j] : Li[(long)j * R + i]);
                 Eb[(long)i * R + j] = (float)(l + yi * y[j]);
             }
         }
@@ -222,21 +235,22 @@ __global__ __launch_bounds__(256) void k_tv_finish(const double *__restrict__ Li
 
 // Extraction only: e_h = X (X' aux) and diag(L^-1) = row norms^2 of X, with X = U^-1 (upper triangular) left by
 // the blocked inverse -- the R^3 product X X' is never formed when no accumulator needs L^-1 itself.
-__global__ __launch_bounds__(256) void k_tv_finish_tri(const double *__restrict__ X, int R, const double *__restrict__ aux,
+template <typename T>
+__global__ __launch_bounds__(256) void k_tv_finish_tri(const T *__restrict__ X, int R, const double *__restrict__ aux,
                                                        double *__restrict__ e_h, float *__restrict__ e_h32,
                                                        double *__restrict__ iv_sigma)
 {
     extern __shared__ double sh[];  // aux[R], y[R]
     double *ax = sh, *y = sh + R;
     const long b = blockIdx.x;
-    const double *Xi = X + b * (long)R * R;
+    const T *Xi = X + b * (long)R * R;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int i = t; i < R; i += 256) ax[i] = aux[b * R + i];
     __syncthreads();
     // y = X' aux: y[j] = sum_{i<=j} X[i][j] aux[i]   (column sweep, coalesced along j)
     for (int j = t; j < R; j += 256) {
         double s = 0.0;
-        for (int i = 0; i <= j; ++i) s += Xi[(long)i * R + j] * ax[i];
+        for (int i = 0; i <= j; ++i) s += (double)Xi[(long)i * R + j] * ax[i];
         y[j] = s;
     }
     __syncthreads();
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(256) void k_tv_finish_tri(const double *__restrict_
     for (int i = wave; i < R; i += 4) {
         double s = 0.0, d = 0.0;
         for (int j = i + lane; j < R; j += 64) {
-            const double x = Xi[(long)i * R + j];
+            const double x = (double)Xi[(long)i * R + j];
             s += x * y[j];
             d += x * x;
         }
@@ -267,13 +281,14 @@ __global__ __launch_bounds__(256) void k_tv_finish_tri(const double *__restrict_
 //   forward   U' y = aux :  y_k = W_k' (aux_k - sum_{i < k} U[i, k]' y_i)
 //   backward  U  x = y   :  x_k = W_k  (y_k   - sum_{j > k} U[k, j]  x_j)
 // One workgroup (4 waves) per session, y / x in LDS.
-__global__ __launch_bounds__(256) void k_tv_solve(const double *__restrict__ Ub, int R, const double *__restrict__ aux,
+template <typename T>
+__global__ __launch_bounds__(256) void k_tv_solve(const T *__restrict__ Ub, int R, const double *__restrict__ aux,
                                                   double *__restrict__ e_h, float *__restrict__ e_h32)
 {
     extern __shared__ double sh[];          // y[R] (overwritten by x), t[CH_BLK], part[4][CH_BLK]
     double *y = sh, *tv = sh + R, *part = sh + R + CH_BLK;
     const long b = blockIdx.x;
-    const double *U = Ub + b * (long)R * R;
+    const T *U = Ub + b * (long)R * R;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int Kb = (R + CH_BLK - 1) / CH_BLK;
     for (int i = t; i < R; i += 256) y[i] = aux[b * R + i];
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(256) void k_tv_solve(const double *__restrict__ Ub,
         // column sums over the rows above the block: lane = column, wave = row phase (coalesced along the row)
         double s = 0.0;
         if (lane < bs)
-            for (int i = wave; i < r0; i += 4) s += U[(long)i * R + r0 + lane] * y[i];
+            for (int i = wave; i < r0; i += 4) s += (double)U[(long)i * R + r0 + lane] * y[i];
         part[wave * CH_BLK + lane] = s;
         __syncthreads();
         if (t < bs) tv[t] = y[r0 + t] - ((part[t] + part[CH_BLK + t]) + (part[2 * CH_BLK + t] + part[3 * CH_BLK + t]));
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(256) void k_tv_solve(const double *__restrict__ Ub,
         // y_k = W_k' t : y[c] = sum_{i <= c} W[i][c] t[i]
         s = 0.0;
         if (lane < bs)
-            for (int i = wave; i <= lane; i += 4) s += U[(long)(r0 + i) * R + r0 + lane] * tv[i];
+            for (int i = wave; i <= lane; i += 4) s += (double)U[(long)(r0 + i) * R + r0 + lane] * tv[i];
         part[wave * CH_BLK + lane] = s;
         __syncthreads();
         if (t < bs) y[r0 + t] = (part[t] + part[CH_BLK + t]) + (part[2 * CH_BLK + t] + part[3 * CH_BLK + t]);
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(256) void k_tv_solve(const double *__restrict__ Ub,
         const int r0 = k * CH_BLK, bs = (R - r0 < CH_BLK) ? (R - r0) : CH_BLK, c0 = r0 + bs;
         for (int r = wave; r < bs; r += 4) {
             double s = 0.0;
-            for (int j = c0 + lane; j < R; j += 64) s += U[(long)(r0 + r) * R + j] * y[j];
+            for (int j = c0 + lane; j < R; j += 64) s += (double)U[(long)(r0 + r) * R + j] * y[j];
 #pragma unroll
             for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
             if (lane == 0) tv[r] = y[r0 + r] - s;
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(256) void k_tv_solve(const double *__restrict__ Ub,
         __syncthreads();
         // x_k = W_k s : x[r] = sum_{c >= r} W[r][c] s[c]
         for (int r = wave; r < bs; r += 4) {
-            double s = (lane >= r && lane < bs) ? U[(long)(r0 + r) * R + r0 + lane] * tv[lane] : 0.0;
+            double s = (lane >= r && lane < bs) ? (double)U[(long)(r0 + r) * R + r0 + lane] * tv[lane] : 0.0;
 #pragma unroll
             for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
             if (lane == 0) y[r0 + r] = s;
@@ -358,9 +373,11 @@ __global__ __launch_bounds__(256) void k_ehh_colsum_add(const double *__restrict
 //   Mb  [nb][R][R] f64, destroyed (ends as X = U^-1)
 //   out [nb][R][R] f64 = M^-1 (upper 64-tiles only when upper_only)
 //   Tb  [nb][CH_BLK][R] f64 scratch
-static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int nb, int R, int add_identity,
+template <typename T>
+static int blocked_inverse(SkmCtx *ctx, T *Mb, T *out, T *Tb, int nb, int R, int add_identity,
                            int upper_only, hipStream_t st, bool factor_only = false)
 {
+    constexpr int KIND = sizeof(T) == 8 ? SKM_GEMM_F64_F64 : SKM_GEMM_F32S_F32;
     const long RR = (long)R * R;
     const int Kb = (R + CH_BLK - 1) / CH_BLK;
     int rc;
@@ -377,21 +394,21 @@ static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int
             u.beta = 1.0;
             u.tile_mask = 1;
             u.sA = u.sB = u.sC = RR;
-            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, u, nb, st, "k_gemm_chol_update"))) return rc;
+            if ((rc = skm_gemm_launch(ctx, KIND, u, nb, st, "k_gemm_chol_update"))) return rc;
         }
         {
             SkmProfScope ps(ctx, "k_chol_diag", st);
-            hipLaunchKernelGGL(k_chol_diag, dim3((nb + 3) / 4), dim3(256), 0, st, Mb + (long)r0 * R + r0, RR, R, bs,
+            hipLaunchKernelGGL(k_chol_diag<T>, dim3((nb + 3) / 4), dim3(256), 0, st, Mb + (long)r0 * R + r0, RR, R, bs,
                                add_identity, nb);
         }
         SKM_HIP(hipGetLastError());
         if (rem <= 0) continue;
-        double *panel = Mb + (long)r0 * R + r0 + bs;
+        T *panel = Mb + (long)r0 * R + r0 + bs;
         // U[k, j>k] = W_k' M[k, j>k]   (in place: every tile reads its whole K range before it writes)
         GemmArgs g = skm_gemm_args(Mb + (long)r0 * R + r0, panel, panel, bs, rem, bs, R, R, R);
         g.transA = 1;
         g.sA = g.sB = g.sC = RR;
-        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, g, nb, st, "k_gemm_chol_panel"))) return rc;
+        if ((rc = skm_gemm_launch(ctx, KIND, g, nb, st, "k_gemm_chol_panel"))) return rc;
     }
     if (factor_only) return SKM_OK;   // block rows hold [W_k | U[k, j > k]]: enough for triangular solves
     // X = U^-1 in place, block rows bottom-up (diagonal blocks already hold W_i = U_ii^-1)
@@ -401,12 +418,12 @@ static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int
         t.sA = t.sB = RR;
         t.sC = (long)CH_BLK * R;
         t.ktrim = 1;        // X[c0:, c0:] is upper triangular
-        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, t, nb, st, "k_gemm_trinv_a"))) return rc;
+        if ((rc = skm_gemm_launch(ctx, KIND, t, nb, st, "k_gemm_trinv_a"))) return rc;
         GemmArgs x = skm_gemm_args(Mb + (long)r0 * R + r0, Tb, Mb + (long)r0 * R + c0, bs, rem, bs, R, R, R);
         x.alpha = -1.0;
         x.sA = x.sC = RR;
         x.sB = (long)CH_BLK * R;
-        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, x, nb, st, "k_gemm_trinv_b"))) return rc;
+        if ((rc = skm_gemm_launch(ctx, KIND, x, nb, st, "k_gemm_trinv_b"))) return rc;
     }
     if (!out) return SKM_OK;   // the caller works with X = U^-1 itself
     // M^-1 = X X'
@@ -415,7 +432,7 @@ static int blocked_inverse(SkmCtx *ctx, double *Mb, double *out, double *Tb, int
     p.tile_mask = upper_only ? 1 : 0;
     p.ktrim = 2;            // X upper triangular: (X X')[i][j] sums k >= max(i, j)
     p.sA = p.sB = p.sC = RR;
-    return skm_gemm_launch(ctx, SKM_GEMM_F64_F64, p, nb, st, "k_gemm_xxt");
+    return skm_gemm_launch(ctx, KIND, p, nb, st, "k_gemm_xxt");
 }
 
 struct TvWs {
@@ -464,6 +481,64 @@ static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0, int D = 0)
     }
     w.total = off;
     return w;
+}
+
+// Precision of the per-session chain L -> Cholesky -> (U^-1 -> L^-1).  Default float32 ("fp32 compute, fp64 final
+// reductions"): the batched 64-wide panel products of the chain are bound by HBM bytes (4.3 TB/s of minimal traffic in
+// float64 whatever the panel, tools/time_chain_gemm.py), so float32 storage halves their time; L has eigenvalues >= 1
+// and e_h costs cond(L) * 6e-8.  SKM_TV_CHAIN=f64 keeps the float64 chain (the M-step is float64 either way).
+static bool tv_chain_f64()
+{
+    const char *e = getenv("SKM_TV_CHAIN");
+    return e && (strcmp(e, "f64") == 0 || strcmp(e, "F64") == 0);
+}
+
+struct TvBatch {
+    const float *naug, *G;
+    const int *cmap;
+    const double *aux;
+    double *e_h, *iv_sigma;
+    float *eh32, *E;
+    int nb, NT, C, R;
+    long ldn;
+    bool train;
+};
+
+// One batch of sessions: L = sum_c N_sc G_c (identity added by the diagonal-block kernel), blocked factorisation /
+// inverse, e_h (+ iv_sigma, + e_hh for training).  T is the type the matrices are stored and factored in.
+template <typename T>
+static int tv_batch_chain(SkmCtx *ctx, const TvBatch &b, char *mb_, char *linv_, char *tb_, hipStream_t st)
+{
+    T *Mb = reinterpret_cast<T *>(mb_), *Linv = reinterpret_cast<T *>(linv_), *Tb = reinterpret_cast<T *>(tb_);
+    const int R = b.R, nb = b.nb;
+    const long RR = (long)R * R;
+    int rc;
+    SKM_HIP(hipMemsetAsync(Mb, 0, (size_t)nb * RR * sizeof(T), st));
+    GemmArgs l = skm_gemm_args(b.naug, b.G, Mb, nb, b.NT, b.C, b.ldn, RR, RR);
+    l.colmap = b.cmap;
+    l.colmap_vec = (R % 4 == 0);
+    l.swz = 1;          // the session tiles of one G column tile share it in one XCD's L2
+    // K = C float32 MFMA terms per entry, accumulated in float32 like the <= `batch` terms of the A accumulation
+    // (the operands are float32 already; ~sqrt(C) * 6e-8 on top of their rounding)
+    if ((rc = skm_gemm_launch(ctx, sizeof(T) == 8 ? SKM_GEMM_F32_F64OUT : SKM_GEMM_F32_F32, l, 1, st, "k_gemm_lbuild")))
+        return rc;
+    const bool solve_only = !b.train && !b.iv_sigma;
+    if ((rc = blocked_inverse<T>(ctx, Mb, b.train ? Linv : nullptr, Tb, nb, R, 1, 1, st, solve_only))) return rc;
+    if (solve_only) {
+        SkmProfScope ps(ctx, "k_tv_solve", st);
+        hipLaunchKernelGGL(k_tv_solve<T>, dim3(nb), dim3(256), (R + 5 * CH_BLK) * sizeof(double), st, Mb, R, b.aux, b.e_h,
+                           b.eh32);
+    } else if (!b.train) {
+        SkmProfScope ps(ctx, "k_tv_finish", st);
+        hipLaunchKernelGGL(k_tv_finish_tri<T>, dim3(nb), dim3(256), 2 * R * sizeof(double), st, Mb, R, b.aux, b.e_h, b.eh32,
+                           b.iv_sigma);
+    } else {
+        SkmProfScope ps(ctx, "k_tv_finish", st);
+        hipLaunchKernelGGL(k_tv_finish<T>, dim3(nb), dim3(256), 2 * R * sizeof(double), st, Linv, R, b.aux, b.e_h, b.eh32,
+                           b.iv_sigma, b.E);
+    }
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
 }
 
 extern "C" int skm_tv_naug_stride(int C) { return tv_ldn(C); }
@@ -529,10 +604,7 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
     }
     hipStream_t st = (hipStream_t)stream;
     char *ws = static_cast<char *>(ws_);
-    double *Mb = reinterpret_cast<double *>(ws + w.off_mb);
-    double *Linv = reinterpret_cast<double *>(ws + w.off_linv);
     float *E = reinterpret_cast<float *>(ws + w.off_e);
-    double *Tb = reinterpret_cast<double *>(ws + w.off_tb);
     double *aux = reinterpret_cast<double *>(ws + w.off_aux);
     float *eh32 = reinterpret_cast<float *>(ws + w.off_eh32);
     const long RR = (long)R * R, CD = (long)C * D, ldn = tv_ldn(C);
@@ -575,34 +647,27 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
             if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, g, 1, st, "k_gemm_aux"))) return rc;
         }
     }
+    const bool chain64 = tv_chain_f64();
     for (long b0 = 0; b0 < S; b0 += batch) {
         const int nb = (int)((S - b0) < batch ? (S - b0) : batch);
-        SKM_HIP(hipMemsetAsync(Mb, 0, (size_t)nb * RR * sizeof(double), st));
-        // L = sum_c N_sc G_c (identity added by the diagonal-block kernel), rows cut at their diagonal block
-        GemmArgs l = skm_gemm_args(naug + b0 * ldn, G, Mb, nb, NT, C, ldn, RR, RR);
-        l.colmap = cmap;
-        l.colmap_vec = (R % 4 == 0);
-        l.swz = 1;          // the session tiles of one G column tile share it in one XCD's L2
-        // K = C float32 MFMA terms per entry, accumulated in float32 like the <= `batch` terms of the A accumulation
-        // below (the operands are float32 already; ~sqrt(C) * 6e-8 on top of their rounding), stored as float64
-        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, l, 1, st, "k_gemm_lbuild"))) return rc;
-        const bool solve_only = !train && !iv_sigma;
-        if ((rc = blocked_inverse(ctx, Mb, train ? Linv : nullptr, Tb, nb, R, 1, 1, st, solve_only))) return rc;
-        if (solve_only) {
-            SkmProfScope ps(ctx, "k_tv_solve", st);
-            hipLaunchKernelGGL(k_tv_solve, dim3(nb), dim3(256), (R + 5 * CH_BLK) * sizeof(double), st, Mb, R,
-                               aux + b0 * R, e_h + b0 * R, eh32 + b0 * R);
-        } else if (!train) {
-            SkmProfScope ps(ctx, "k_tv_finish", st);
-            hipLaunchKernelGGL(k_tv_finish_tri, dim3(nb), dim3(256), 2 * R * sizeof(double), st, Mb, R, aux + b0 * R,
-                               e_h + b0 * R, eh32 + b0 * R, iv_sigma ? iv_sigma + b0 * R : nullptr);
-        } else {
-            SkmProfScope ps(ctx, "k_tv_finish", st);
-            hipLaunchKernelGGL(k_tv_finish, dim3(nb), dim3(256), 2 * R * sizeof(double), st, Linv, R, aux + b0 * R,
-                               e_h + b0 * R, eh32 + b0 * R, iv_sigma ? iv_sigma + b0 * R : nullptr,
-                               train ? E : nullptr);
-        }
-        SKM_HIP(hipGetLastError());
+        TvBatch tb;
+        tb.naug = naug + b0 * ldn;
+        tb.G = G;
+        tb.cmap = cmap;
+        tb.aux = aux + b0 * R;
+        tb.e_h = e_h + b0 * R;
+        tb.eh32 = eh32 + b0 * R;
+        tb.iv_sigma = iv_sigma ? iv_sigma + b0 * R : nullptr;
+        tb.E = train ? E : nullptr;
+        tb.nb = nb;
+        tb.NT = NT;
+        tb.C = C;
+        tb.R = R;
+        tb.ldn = ldn;
+        tb.train = train;
+        rc = chain64 ? tv_batch_chain<double>(ctx, tb, ws + w.off_mb, ws + w.off_linv, ws + w.off_tb, st)
+                     : tv_batch_chain<float>(ctx, tb, ws + w.off_mb, ws + w.off_linv, ws + w.off_tb, st);
+        if (rc) return rc;
         if (train) {
             // A[c] += sum_s N_sc e_hh(s).  Row C of A_aug (= _R, the plain sum of e_hh over the sessions) is NOT taken
             // through the ones column of naug: C + 1 = 2049 rows would open a 17th row of 128-wide tiles for one
@@ -660,7 +725,7 @@ extern "C" int skm_tv_mstep(void *ctx_, double *A_aug, const double *Cacc, int C
         const int nb = (C - c0) < batch ? (C - c0) : batch;
         // A_c^-1 = X X' with X = U^-1 (upper triangular, left in place of A_c): T_c = (C_c' X) X' is two D x R x R
         // products per component instead of the R^3 product X X' plus one
-        if ((rc = blocked_inverse(ctx, A_aug + c0 * RR, nullptr, Tb, nb, R, 0, 0, st))) return rc;
+        if ((rc = blocked_inverse<double>(ctx, A_aug + c0 * RR, (double *)nullptr, Tb, nb, R, 0, 0, st))) return rc;
         double *Y = Ybuf;   // [nb][D][R]
         GemmArgs g = skm_gemm_args(Cacc + (long)c0 * D, A_aug + c0 * RR, Y, D, R, R, CD, R, R);
         g.transA = 1;       // Y[d][r] = sum_k C[k][cD+d] X[k][r]

@@ -436,7 +436,7 @@ class HipEngine(object):
         return out, lab_out, out_off
 
     # ------------------------------------------------------------------ total variability
-    GEMM_F32_F32, GEMM_F32_F64ACC, GEMM_F64_F64, GEMM_F64_F32OUT = 0, 1, 2, 3
+    GEMM_F32_F32, GEMM_F32_F64ACC, GEMM_F64_F64, GEMM_F64_F32OUT, GEMM_F32_F64OUT, GEMM_F32S_F32 = 0, 1, 2, 3, 4, 5
 
     def gemm(self, A, B, C=None, transA=False, transB=False, alpha=1.0, beta=0.0, kind=None):
         """C = alpha op(A) op(B) + beta C on 2-D contiguous device tensors (float32 or float64)."""
@@ -447,7 +447,7 @@ class HipEngine(object):
         assert K == K2, (A.shape, B.shape, transA, transB)
         if kind is None:
             kind = self.GEMM_F64_F64 if A.dtype == torch.float64 else self.GEMM_F32_F32
-        out_dtype = torch.float32 if kind in (self.GEMM_F32_F32, self.GEMM_F64_F32OUT) else torch.float64
+        out_dtype = torch.float32 if kind in (self.GEMM_F32_F32, self.GEMM_F64_F32OUT, self.GEMM_F32S_F32) else torch.float64
         if C is None:
             C = torch.empty((M, N), dtype=out_dtype, device=self.device)
             beta = 0.0

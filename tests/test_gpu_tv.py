@@ -50,7 +50,7 @@ def dev(eng, a, dtype=None):
 
 @pytest.mark.parametrize("M,N,K,ta,tb", [(64, 64, 64, 0, 0), (130, 70, 33, 0, 0), (33, 257, 100, 1, 0),
                                           (200, 129, 17, 0, 1), (65, 66, 300, 1, 1), (1, 400, 1000, 0, 0)])
-@pytest.mark.parametrize("kind", ["f32", "f32acc", "f64"])
+@pytest.mark.parametrize("kind", ["f32", "f32acc", "f32small", "f64"])
 def test_gemm(eng, M, N, K, ta, tb, kind):
     rs = np.random.RandomState(M + N + K)
     A = rs.randn(*((K, M) if ta else (M, K)))
@@ -61,7 +61,7 @@ def test_gemm(eng, M, N, K, ta, tb, kind):
         C = eng.gemm(dev(eng, A), dev(eng, B), transA=ta, transB=tb)
         tol = 1e-13
     else:
-        k = eng.GEMM_F32_F32 if kind == "f32" else eng.GEMM_F32_F64ACC
+        k = {"f32": eng.GEMM_F32_F32, "f32acc": eng.GEMM_F32_F64ACC, "f32small": eng.GEMM_F32S_F32}[kind]
         C = eng.gemm(dev(eng, A, torch.float32), dev(eng, B, torch.float32), transA=ta, transB=tb, kind=k)
         ref = (A.astype(np.float32).astype(np.float64).T if ta else A.astype(np.float32).astype(np.float64)).dot(
             B.astype(np.float32).astype(np.float64).T if tb else B.astype(np.float32).astype(np.float64))
@@ -136,9 +136,12 @@ def test_estep_accumulators_and_mstep(eng, case):
     A, Cc, e_h, sig, A_dev, C_dev = _accumulators(eng, gmm, s0, s1, Fm, batch)
     rA, rC, rR = orc.tv_accumulate(s0, s1, gmm, Fm, batch_size=300)
     rR = rR * s0.shape[0]
-    assert rel(_upper_packed(A[:C]), rA) < 2e-5
-    assert rel(Cc, rC) < 2e-5
-    assert rel(_upper_packed(A[C]), rR) < 2e-5
+    # r400 (R > C*D: L is the worst-conditioned case on purpose) sits at 2.0e-5 with the float32 per-session chain,
+    # 1.5e-5 with SKM_TV_CHAIN=f64; the float32 Gram matrices set the floor either way
+    tol = 4e-5 if case == "r400" else 2e-5
+    assert rel(_upper_packed(A[:C]), rA) < tol
+    assert rel(Cc, rC) < tol
+    assert rel(_upper_packed(A[C]), rR) < tol
     iv, iv_sigma = orc.extract_ivectors(s0, s1, gmm, Fm)
     # r400 has R > C*D: T'T is rank deficient and L = I + sum N_c G_c is the worst-conditioned case on
     # purpose; the float32 Gram matrices then cost cond(L) * 6e-8 on e_h
@@ -153,7 +156,7 @@ def test_estep_accumulators_and_mstep(eng, case):
         assert none is None
         e_s = eng.to_host(e_s)
         assert rel(e_s, iv) < (1e-4 if case == "r400" else 2e-5)
-        assert rel(e_s, e_h) < (1e-5 if case == "r400" else 1e-9)
+        assert rel(e_s, e_h) < (5e-5 if case == "r400" else 1e-6)     # two routes through the float32 chain
         assert min_cosine(e_s, iv) > 0.9999
     # M-step from the DEVICE accumulators against the oracle's M-step from ITS accumulators
     Fn = eng.to_host(eng.tv_mstep(A_dev, C_dev, C, D, R))
@@ -285,7 +288,8 @@ def test_full_size_invariants_cfg5_shape(eng):
         return A, Cc, e, s
     A, Cc, e_h, sig = train(slice(0, S), 256)
     e_solve, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=512, uncertainty=False)
-    assert rel(eng.to_host(e_solve), eng.to_host(e_h)) < 1e-8
+    # two routes (triangular solves / explicit inverse) through the float32 chain (1e-8 with SKM_TV_CHAIN=f64)
+    assert rel(eng.to_host(e_solve), eng.to_host(e_h)) < 5e-6
 
     # the linear system, three sessions, host float64
     e_host, s_host, n_host, f_host = eng.to_host(e_h), eng.to_host(sig), eng.to_host(stat0), eng.to_host(ft)
