@@ -440,12 +440,15 @@ struct TvWs {
     int ksplit;
 };
 
-// split-K factor of the aux = f~ T GEMM: few sessions give too few 128 x 128 output tiles to fill the chip
+// split-K factor of the aux = f~ T GEMM.  Every K chunk is a launch of its own (float32 sums over TV_AUX_CHUNK terms,
+// float64 across chunks), and a launch whose 128 x 128 output tiles make only a few rounds over the 2 x CU resident
+// workgroups idles in its last round: 50 000 sessions x R = 400 are 1564 tiles = 3.05 rounds, a quarter of the fourth
+// lost sixty times.  Splitting K over slabs puts several chunks into one launch until it has at least 8 rounds.
 static int tv_ksplit(int cu, long S, int R, int C)
 {
     const long tiles = ((S + 127) / 128) * ((R + 127) / 128);
     int ks = 1;
-    while (ks < 16 && tiles * ks < 2L * cu && C % (ks * 2) == 0) ks *= 2;
+    while (ks < 16 && tiles * ks < 16L * cu && C % (ks * 2) == 0) ks *= 2;
     return ks;
 }
 
