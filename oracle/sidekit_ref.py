@@ -700,3 +700,42 @@ def fast_plda_scores(enroll_iv, test_iv, mu, F, Sigma, p_known=0.0, scaling_fact
             out[i] = sc[i] - np.log(p_known * ex[~(np.arange(N) == i)].sum(axis=0) / (N - 1) + (1 - p_known))
         sc = out
     return sc
+
+
+def plda_train(modelset, x, rank_f, nb_iter=10, scaling_factor=1.0):
+    """FactorAnalyser.plda (sidekit/factor_analyser.py:810-910) for i-vectors x (S x R, stat0 = 1): simplified PLDA, EM
+    with minimum divergence.  Returns (mean, F, Sigma).  Per-class loop as fa_model_loop (:168-206, Sigma.ndim == 2
+    branch: one inverse per distinct session count)."""
+    x = np.asarray(x, dtype=np.float64)
+    mean = x.mean(axis=0)                                            # :832
+    Sigma = total_covariance(x)                                      # :833
+    uniq, rows = _classes(modelset)                                  # sum_stat_per_model (statserver.py:1206-1226)
+    s0 = np.array([float(len(r)) for r in rows]) * scaling_factor    # :840
+    s1 = np.array([x[r].sum(axis=0) for r in rows]) * scaling_factor # :841
+    session_per_model = np.array([float(len(r)) for r in rows]) * scaling_factor   # :842
+    sigma_obs = total_covariance(x)                                  # :845
+    evals, evecs = scipy.linalg.eigh(sigma_obs)
+    idx = np.argsort(evals)[::-1]
+    F = evecs.real[:, idx[:rank_f]]                                  # :846-849
+    K = len(rows)
+    for _ in range(nb_iter):
+        ev, evec = scipy.linalg.eigh(Sigma)                          # whiten_stat1 and :865-871 use the same factor
+        ind = ev.real.argsort()[::-1]
+        sqr_inv_sigma = np.dot(evec.real[:, ind], np.diag(1 / np.sqrt(ev.real[ind])))
+        w1 = np.dot(s1 - s0[:, None] * mean, sqr_inv_sigma)          # statserver.py:690-697, 747-764
+        F = sqr_inv_sigma.T.dot(F)                                   # :871
+        A = F.T.dot(F)
+        inv_lambda = {n: scipy.linalg.inv(n * A + np.eye(rank_f)) for n in np.unique(s0)}
+        e_h = np.zeros((K, rank_f))
+        e_hh = np.zeros((K, rank_f, rank_f))
+        for i in range(K):
+            il = inv_lambda[s0[i]]
+            e_h[i] = F.T.dot(w1[i]).dot(il)
+            e_hh[i] = il + np.outer(e_h[i], e_h[i])
+        _R = e_hh.sum(axis=0) / session_per_model.shape[0]           # :891
+        _C = e_h.T.dot(w1).dot(scipy.linalg.inv(sqr_inv_sigma))      # :893
+        _A = np.einsum('ijk,i->jk', e_hh, s0)                        # :894
+        F = scipy.linalg.solve(_A, _C).T                             # :897
+        Sigma = sigma_obs - F.dot(_C) / session_per_model.sum()      # :900
+        F = F.dot(scipy.linalg.cholesky(_R))                         # :903
+    return mean, F, Sigma

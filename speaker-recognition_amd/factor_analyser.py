@@ -7,7 +7,7 @@ rank's sessions live in HBM for the whole training run and every EM iteration is
 batched MFMA GEMMs (csrc/skm_tv.hip).  With torch.distributed initialised the sessions are cut
 over the ranks like numpy.array_split (sidekit_mpi.py:118-123), the accumulators _A, _C, _R are
 summed with all-reduce (replaces the Reduce calls of sidekit_mpi.py:186-214) and every rank runs
-the same M-step.  PLDA (factor_analyser.py:810-910) is out of scope of this path.
+the same M-step.  PLDA training (factor_analyser.py:810-910), the step after extraction, is `plda` below.
 """
 import copy
 import os
@@ -264,6 +264,78 @@ class FactorAnalyser(object):
         stat_server.whiten_stat1(ubm.get_mean_super_vector(), 1. / ubm.get_invcov_super_vector())
         self._train(None, ubm, tv_rank, nb_iter, min_div, tv_init, None, save_init, output_file_name,
                     always_write=True, resident=(ft, naug, n))
+
+    # ------------------------------------------------------------------ PLDA (next row: the step after extraction)
+    def plda(self, stat_server, rank_f, nb_iter=10, scaling_factor=1., output_file_name=None, save_partial=False):
+        """Simplified PLDA (between-class subspace F, full residual covariance Sigma) by EM with minimum divergence --
+        sidekit/factor_analyser.py:810-910 with its per-class loop fa_model_loop (:168-206).
+
+        The reference walks the classes in Python: one rank x rank `inv` per distinct session count, then per class two
+        small `dot`s and an outer product into a K x rank x rank array.  Here the classes are sorted by session count
+        once; per iteration the K x R whitening and projection are two float64 MFMA GEMMs, e_h is one GEMM per distinct
+        count on a contiguous row block, and the sums over classes of e_hh (weighted and unweighted) never form the
+        K x rank x rank array: sum_i e_hh[i] = sum_u n_u inv_lambda_u + e_h'e_h.  The R x R eigen-decompositions,
+        inverses and the rank x rank solve / Cholesky are single host LAPACK calls, as in the reference.  Every rank of
+        a distributed job computes the same (small) model."""
+        import scipy.linalg
+        eng = self.engine
+        torch = eng.torch
+        self.mean = stat_server.get_mean_stat1()
+        self.Sigma = stat_server.get_total_covariance_stat1()
+        model_shifted_stat, session_per_model = stat_server.sum_stat_per_model()
+        model_shifted_stat.stat0 *= scaling_factor
+        model_shifted_stat.stat1 *= scaling_factor
+        session_per_model *= scaling_factor
+        sigma_obs = self.Sigma.copy()                       # get_total_covariance_stat1 again in the reference (:845)
+        evals, evecs = scipy.linalg.eigh(sigma_obs)
+        idx = np.argsort(evals)[::-1]
+        self.F = evecs.real[:, idx[:rank_f]]
+
+        n = model_shifted_stat.stat0[:, 0].astype(np.float64)
+        order = np.argsort(n, kind="stable")
+        n_sorted = n[order]
+        uniq, first = np.unique(n_sorted, return_index=True)
+        bounds = list(first) + [n.shape[0]]
+        S1 = eng.rows_center(eng._f64_dev(model_shifted_stat.stat1), src=order)      # classes sorted by count
+        n_col = eng._f64_dev(n_sorted.reshape(-1, 1))
+        K, R = S1.shape
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(eng.device)
+
+        for it in range(nb_iter):
+            eigen_values, eigen_vectors = scipy.linalg.eigh(self.Sigma)
+            ind = eigen_values.real.argsort()[::-1]
+            sqr_inv_sigma = np.dot(eigen_vectors.real[:, ind], np.diag(1 / np.sqrt(eigen_values.real[ind])))
+            # whitened class statistics (stat1 - stat0 mean) Q  (statserver.py:690-697, 747-764)
+            W1 = eng.gemm(S1, dev(sqr_inv_sigma))
+            eng.gemm(n_col, dev(self.mean.reshape(1, -1).dot(sqr_inv_sigma)), C=W1, alpha=-1.0, beta=1.0)
+            self.F = sqr_inv_sigma.T.dot(self.F)
+            A = self.F.T.dot(self.F)
+            aux = eng.gemm(W1, dev(self.F))                                          # K x rank
+            e_h = torch.empty((K, rank_f), dtype=torch.float64, device=eng.device)
+            sum_il = np.zeros((rank_f, rank_f))
+            sum_n_il = np.zeros((rank_f, rank_f))
+            EhEh = torch.zeros((rank_f, rank_f), dtype=torch.float64, device=eng.device)
+            nEhEh = torch.zeros((rank_f, rank_f), dtype=torch.float64, device=eng.device)
+            for u, a, b in zip(uniq, bounds[:-1], bounds[1:]):
+                inv_lambda = scipy.linalg.inv(u * A + np.eye(rank_f))
+                eng.gemm(aux[a:b], dev(inv_lambda), C=e_h[a:b])
+                sum_il += (b - a) * inv_lambda
+                sum_n_il += (b - a) * u * inv_lambda
+                eng.gemm(e_h[a:b], e_h[a:b], C=EhEh, transA=True, beta=1.0)
+                eng.gemm(e_h[a:b], e_h[a:b], C=nEhEh, transA=True, alpha=float(u), beta=1.0)
+            _R = (sum_il + eng.to_host(EhEh)) / session_per_model.shape[0]
+            _C = eng.to_host(eng.gemm(e_h, W1, transA=True)).dot(scipy.linalg.inv(sqr_inv_sigma))
+            _A = sum_n_il + eng.to_host(nEhEh)
+            self.F = scipy.linalg.solve(_A, _C).T
+            self.Sigma = sigma_obs - self.F.dot(_C) / session_per_model.sum()
+            self.F = self.F.dot(scipy.linalg.cholesky(_R))
+            if output_file_name is None:
+                output_file_name = "temporary_plda"
+            if dist.rank() == 0:
+                if save_partial and it < nb_iter - 1:
+                    self.write(output_file_name + "_it-{}".format(it) + self._ext())
+                elif it == nb_iter - 1:
+                    self.write(output_file_name + self._ext())
 
     # ------------------------------------------------------------------ extraction
     def _extract(self, ft, naug, ubm, batch, uncertainty):

@@ -166,6 +166,9 @@ class OracleEngine(object):
         r = alpha * a.dot(B.numpy().T if transB else B.numpy())
         if C is not None and beta != 0.0:
             r = r + beta * C.numpy()
+        if C is not None:                       # the HIP engine writes C in place
+            C.copy_(torch.from_numpy(np.ascontiguousarray(r)))
+            return C
         return torch.from_numpy(np.ascontiguousarray(r))
 
     # i-vector back-end reductions (numpy statements of the skm_class_sums / skm_rows_center / skm_row_dot /

@@ -30,6 +30,33 @@ def test_backend_vs_reference_golden(sk, eng):
     run_backend_case(sk, eng)
 
 
+def test_plda_training_vs_reference_golden(sk, eng, tmp_path):
+    """FactorAnalyser.plda (factor_analyser.py:810-910) on the device primitives against the real reference."""
+    from plda_case import run_plda_case
+    run_plda_case(sk, eng, tmp_path)
+
+
+def test_plda_training_larger_vs_oracle(sk, eng, tmp_path):
+    """4000 i-vectors of rank 200 from 600 speakers (1..14 sessions, shuffled), subspace rank 60, two iterations."""
+    rs = np.random.RandomState(12)
+    R, K, rank_f = 200, 600, 60
+    V = rs.randn(R, rank_f)
+    nsess = rs.randint(1, 15, size=K)
+    models = np.repeat(np.array(["s%04d" % k for k in range(K)]), nsess)
+    X = np.repeat(rs.randn(K, rank_f).dot(V.T), nsess, axis=0) + rs.randn(models.shape[0], R) * 0.8 + 0.1
+    perm = rs.permutation(models.shape[0])
+    models, X = models[perm], X[perm]
+    ss = _server(sk, eng, models, ["g%05d" % i for i in range(models.shape[0])], X)
+    fa = sk.FactorAnalyser(engine=eng)
+    fa.plda(ss, rank_f, nb_iter=2, output_file_name=str(tmp_path / "plda_big"))
+    m, F, S = orc.plda_train(models, X, rank_f, nb_iter=2)
+    _close(fa.mean, m, 1e-12)
+    _close(fa.Sigma, S, 1e-8)
+    _close(fa.F.dot(fa.F.T), F.dot(F.T), 1e-8)          # the subspace, free of LAPACK's eigenvector signs
+    sgn = np.sign((fa.F * F).sum(axis=0))
+    _close(fa.F * sgn, F, 1e-7)
+
+
 def test_backend_reductions_ragged_vs_oracle(sk, eng):
     """R = 83 (not a multiple of 64), 700 sessions of 37 speakers with 1..60 sessions each in shuffled order."""
     rs = np.random.RandomState(5)

@@ -275,6 +275,25 @@ def test_iv_backend_host_logic_vs_reference_golden():
     run_backend_case(sk, OracleEngine())
 
 
+def test_plda_training_oracle_vs_reference_golden():
+    """oracle/sidekit_ref.plda_train against the real reference's FactorAnalyser.plda (3 iterations, 1 iteration, a
+    scaling factor)."""
+    g = golden("plda.npz")
+    for tag, kw in (("it3", dict(nb_iter=3)), ("it1", dict(nb_iter=1)), ("scaled", dict(nb_iter=2, scaling_factor=0.6))):
+        m, F, S = orc.plda_train(g["modelset"], g["stat1"], int(g["rank_f"]), **kw)
+        for a, b in ((m, g["mean_" + tag]), (F, g["F_" + tag]), (S, g["Sigma_" + tag])):
+            assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+
+
+def test_plda_training_host_logic_vs_reference_golden(tmp_path):
+    """The drop-in FactorAnalyser.plda (class sorting by session count, grouped inverses, the sums that replace the
+    K x rank x rank array, file products) on the oracle-backed engine, no GPU, against the real reference."""
+    import sidekit_amd as sk
+    from fake_engine import OracleEngine
+    from plda_case import run_plda_case
+    run_plda_case(sk, OracleEngine(), tmp_path)
+
+
 def _sliding_cases():
     g = golden("post_processing_sliding.npz")
     for i in range(int(g["n_cases"])):

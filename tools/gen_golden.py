@@ -619,6 +619,37 @@ def gen_tv_big(sidekit, tmp):
     print("tv_big F", fa.F.shape, "|F|max", np.abs(fa.F).max(), "iv", ivs.stat1.shape)
 
 
+def gen_plda(sidekit, tmp):
+    """PLDA training (FactorAnalyser.plda, factor_analyser.py:810-910) on synthetic i-vectors: speakers with 1..8
+    sessions in shuffled order; plain run (3 iterations), a scaling factor, and one iteration alone (the partial
+    product of the first).  The model files go through the stand-in h5py into a temporary directory."""
+    rs = np.random.RandomState(2024)
+    R, K, rank_f = 24, 40, 8
+    nsess = rs.randint(1, 9, size=K)
+    V = rs.randn(R, rank_f) * 1.2
+    models, rows = [], []
+    for k in range(K):
+        y = rs.randn(rank_f)
+        for j in range(nsess[k]):
+            models.append("spk%02d" % k)
+            rows.append(V.dot(y) + rs.randn(R) * rs.uniform(0.4, 1.1, size=R) + 0.3)
+    order = rs.permutation(len(models))
+    ss = sidekit.StatServer()
+    ss.modelset = np.array([models[i] for i in order])
+    ss.segset = np.array(["seg%03d" % i for i in range(len(models))])
+    ss.start = np.empty(len(models), "|O")
+    ss.stop = np.empty(len(models), "|O")
+    ss.stat0 = np.ones((len(models), 1))
+    ss.stat1 = np.array([rows[i] for i in order], dtype=np.float64)
+    out = dict(R=R, rank_f=rank_f, modelset=ss.modelset, segset=ss.segset, stat1=ss.stat1.copy())
+    for tag, kw in (("it3", dict(nb_iter=3)), ("it1", dict(nb_iter=1)), ("scaled", dict(nb_iter=2, scaling_factor=0.6))):
+        fa = sidekit.FactorAnalyser()
+        fa.plda(copy.deepcopy(ss), rank_f, output_file_name=os.path.join(tmp, "plda_" + tag), **kw)
+        out["mean_" + tag], out["F_" + tag], out["Sigma_" + tag] = fa.mean, fa.F, fa.Sigma
+    np.savez_compressed(os.path.join(OUT, "plda.npz"), **out)
+    print("plda", ss.stat1.shape, out["F_it3"].shape, float(np.abs(out["Sigma_it3"]).max()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "round2":
@@ -626,6 +657,10 @@ def main():
         gen_em_split_vad(sidekit)
         with tempfile.TemporaryDirectory() as tmp:
             gen_tv_big(sidekit, tmp)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "plda":
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_plda(import_reference(), tmp)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "sliding":
         gen_sliding(import_reference())
@@ -659,6 +694,7 @@ def main():
     gen_em_split_vad(sidekit)
     with tempfile.TemporaryDirectory() as tmp:
         gen_tv_big(sidekit, tmp)
+        gen_plda(sidekit, tmp)
 
 
 if __name__ == "__main__":
