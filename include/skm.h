@@ -285,6 +285,24 @@ int skm_feat_sliding_norm(void *ctx, const void *Y_dev, const void *Yn_dev, int 
                           const int *chunk_sess_dev, const int *chunk_p0_dev, int nchunks, int chunk_len, int win,
                           int reduce, void *stream);
 
+/* The same normalisation for the sessions with MORE than `win` labelled frames, window held in LDS: a workgroup loads
+ * the rows its windows touch once (gathered through idx_dev, 16 columns at a time) instead of three row reads per
+ * output.  Work list entries are chunks of skm_feat_sliding_lds_chunk(in_f64) labelled positions of one session
+ * (chunk_p0 = first position); win <= 601.  Same arguments otherwise; sessions with at most `win` labelled frames go
+ * through skm_feat_sliding_norm. */
+int skm_feat_sliding_lds_chunk(int in_f64);
+int skm_feat_sliding_norm_lds(void *ctx, const void *Y_dev, int in_f64, void *out_dev, int out_f64, int compact, int D,
+                              const int64_t *idx_dev, const int64_t *coff_dev, const int *chunk_sess_dev,
+                              const int *chunk_p0_dev, int nchunks, int win, int reduce, void *stream);
+
+/* Index of the labelled frames of a batch (what the sliding normalisation walks; replaces a prefix sum and a
+ * compaction done with tensor-library calls): idx_dev[k] = row of the k-th labelled frame among rows 0..T-1 (room for T
+ * entries), coff_dev[s] = labelled frames in front of row seg_off_dev[s], s = 0..S (S + 1 entries).  label_dev: one
+ * byte per row, non-zero = labelled (the VAD labels of sidekit/features_server.py:241-244).  No atomics. */
+size_t skm_label_index_workspace_bytes(long T);
+int skm_label_index(void *ctx, const uint8_t *label_dev, long T, const int64_t *seg_off_dev, int S, int64_t *idx_dev,
+                    int64_t *coff_dev, void *ws_dev, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

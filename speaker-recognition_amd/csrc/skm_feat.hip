@@ -573,6 +573,88 @@ extern "C" int skm_feat_postproc(void *ctx_, const void *X_dev, int in_f64, long
 }
 
 // ------------------------------------------------------------------------------------------------
+// Index of the labelled frames of a batch (the bookkeeping of the sliding normalisation): idx[k] = row of the k-th
+// labelled frame (rows < T in order), coff[s] = labelled frames in front of row seg_off[s] (S + 1 entries;
+// coff[S] = labelled frames in front of seg_off[S]).  Three steps, no atomics: labelled frames per block of
+// FEAT_IB rows -> exclusive scan -> every wave ranks the labelled frames of its 64-row groups with ballots.
+// ------------------------------------------------------------------------------------------------
+#define FEAT_IB 4096
+__global__ __launch_bounds__(256) void k_label_count(const uint8_t *__restrict__ lab, long T, int64_t *__restrict__ cnt)
+{
+    __shared__ int part[4];
+    const long r0 = (long)blockIdx.x * FEAT_IB;
+    int n = 0;
+    for (long r = r0 + threadIdx.x; r < r0 + FEAT_IB && r < T; r += 256) n += lab[r] ? 1 : 0;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) n += __shfl_xor(n, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = (long)part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void k_label_index(const uint8_t *__restrict__ lab, long T, const int64_t *__restrict__ boff,
+                                                     int64_t *__restrict__ idx)
+{
+    __shared__ int wcnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.x * FEAT_IB;
+    long base = boff[blockIdx.x];
+    // 16 rounds of 256 rows: rank inside the wave by ballot, waves of a round by a 4-entry table
+    for (int it = 0; it < FEAT_IB / 256; ++it) {
+        const long r = r0 + it * 256 + threadIdx.x;
+        const bool on = r < T && lab[r] != 0;
+        const unsigned long long m = __ballot(on);
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            before += (w < wave) ? wcnt[w] : 0;
+            total += wcnt[w];
+        }
+        if (on) idx[base + before + __popcll(m & ((1ull << lane) - 1ull))] = r;
+        base += total;
+        __syncthreads();
+    }
+}
+
+// coff[s] = boff[block of seg_off[s]] + labelled rows of that block in front of seg_off[s]   (one wave per entry)
+__global__ __launch_bounds__(256) void k_label_coff(const uint8_t *__restrict__ lab, long T, const int64_t *__restrict__ boff,
+                                                    const int64_t *__restrict__ seg_off, int S, int64_t *__restrict__ coff)
+{
+    const int lane = threadIdx.x & 63;
+    const long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s > S) return;
+    const long row = seg_off[s] < T ? seg_off[s] : T;
+    const long b = row / FEAT_IB;
+    long n = 0;
+    for (long r = b * FEAT_IB + lane; r < row; r += 64) n += lab[r] ? 1 : 0;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) n += __shfl_xor(n, m);
+    if (lane == 0) coff[s] = boff[b] + n;
+}
+
+extern "C" size_t skm_label_index_workspace_bytes(long T) { return (size_t)(2 * ((T + FEAT_IB - 1) / FEAT_IB + 1) + 2) * 8; }
+
+extern "C" int skm_label_index(void *ctx_, const uint8_t *label, long T, const int64_t *seg_off, int S, int64_t *idx,
+                               int64_t *coff, void *ws, size_t ws_bytes, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && label && T > 0 && seg_off && S >= 0 && idx && coff && ws, "skm_label_index: bad argument");
+    SKM_REQUIRE(ws_bytes >= skm_label_index_workspace_bytes(T), "skm_label_index: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const long nblk = (T + FEAT_IB - 1) / FEAT_IB;
+    int64_t *cnt = static_cast<int64_t *>(ws), *boff = cnt + nblk + 1;
+    SkmProfScope ps(ctx, "k_feat_index", st);
+    hipLaunchKernelGGL(k_label_count, dim3((unsigned)nblk), dim3(256), 0, st, label, T, cnt);
+    hipLaunchKernelGGL(k_feat_scan, dim3(1), dim3(1024), 0, st, cnt, nblk, boff);
+    hipLaunchKernelGGL(k_label_index, dim3((unsigned)nblk), dim3(256), 0, st, label, T, boff, idx);
+    hipLaunchKernelGGL(k_label_coff, dim3((unsigned)((S + 1 + 3) / 4)), dim3(256), 0, st, label, T, boff, seg_off, S, coff);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sliding-window normalisation (features_server.py:282-287 -> frontend/normfeat.py:194-229): mean and sample
 // standard deviation over `win` LABELLED frames centred on each labelled frame, the first / last win/2 positions
 // take the nearest full window; only labelled frames change.  A session with at most `win` labelled frames takes
@@ -582,6 +664,24 @@ extern "C" int skm_feat_postproc(void *ctx_, const void *X_dev, int in_f64, long
 // buffer: windows reach into neighbouring chunks).  idx: row of every labelled frame, coff: labelled frames before
 // each session.  Float64, no atomics.
 // ------------------------------------------------------------------------------------------------
+// One output of the sliding normalisation from the window sums (relative to `pivot`).  A float64 result divides as
+// the reference does; a float32 result (the frames the statistics kernels read) takes the reciprocals in float32 --
+// the float64 divide and square root were most of the kernel's vector instructions.
+template <typename TO>
+__device__ __forceinline__ TO slide_value(double x, double pivot, double sum, double ssq, double w, double inv_w, int reduce)
+{
+    const double v = x - (pivot + (sizeof(TO) == 8 ? sum / w : sum * inv_w));
+    if (!reduce) return (TO)v;
+    if (sizeof(TO) == 8) {
+        double var = (ssq - sum * sum / w) / (w - 1.0);
+        if (var < 0.0) var = 0.0;
+        return (TO)(v / sqrt(var));
+    }
+    float var = (float)((ssq - sum * sum * inv_w) * (1.0 / (w - 1.0)));
+    if (var < 0.f) var = 0.f;
+    return (TO)((float)v / __fsqrt_rn(var));
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void k_feat_sliding(const TI *__restrict__ Y, const TI *__restrict__ Yn,
                                                       TO *__restrict__ out, int compact, int D,
@@ -613,7 +713,7 @@ __global__ __launch_bounds__(256) void k_feat_sliding(const TI *__restrict__ Y, 
     const int64_t *ix = idx + coff[s];
     const long dw = win / 2;
     const long p1 = (p0 + chunk_len < n) ? p0 + chunk_len : n;
-    const double w = (double)win;
+    const double w = (double)win, inv_w = 1.0 / w;
     for (int j = lane; j < D; j += 64) {
         long c = p0 < dw ? dw : (p0 > n - dw - 1 ? n - dw - 1 : p0);
         const double pivot = (double)Y[ix[c - dw] * D + j];
@@ -633,15 +733,129 @@ __global__ __launch_bounds__(256) void k_feat_sliding(const TI *__restrict__ Y, 
                 c = cn;
             }
             const long r = ix[p];
-            double v = (double)Y[r * D + j] - (pivot + sum / w);
-            if (reduce) {
-                double var = (ssq - sum * sum / w) / (w - 1.0);
-                if (var < 0.0) var = 0.0;
-                v = v / sqrt(var);
-            }
-            out[(compact ? coff[s] + p : r) * D + j] = (TO)v;
+            out[(compact ? coff[s] + p : r) * D + j] = slide_value<TO>((double)Y[r * D + j], pivot, sum, ssq, w, inv_w, reduce);
         }
     }
+}
+
+// The same walk with the window in LDS (sessions with more than `win` labelled frames): a workgroup owns a chunk of
+// 16 * SL labelled positions of one session and a block of 16 columns, loads the rows its windows touch --
+// positions [c(p0) - dw, c(p1 - 1) + dw], at most 16 SL + win - 1 rows -- ONCE (64-byte pieces of the rows, gathered
+// through idx), and 16 x 16 threads = (sub-chunk of SL positions, column) slide their window sums over LDS.
+// HBM reads per output row: (16 SL + win) / (16 SL) = 1.35 at SL = 53 (two workgroups per CU) against three row reads per output in the
+// lane-per-column kernel above.  SL = 1 (mod 4) with a row stride of 16 words: the four sub-chunks of a wave start
+// 16 banks apart.
+#define FEAT_SB 16      // columns per block
+template <typename TI, typename TO, int SL>
+__global__ __launch_bounds__(256) void k_feat_sliding_lds(const TI *__restrict__ Y, TO *__restrict__ out, int compact, int D,
+                                                          const int64_t *__restrict__ idx, const int64_t *__restrict__ coff,
+                                                          const int *__restrict__ chunk_sess, const int *__restrict__ chunk_p0,
+                                                          int nchunks, int win, int reduce)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    TI *tile = reinterpret_cast<TI *>(lds_raw);             // [rows][FEAT_SB]
+    // workgroups w, w + 8, w + 16, ... run on one XCD: the column blocks of ONE chunk take ids 8 apart, so the 128-byte
+    // lines their 64-byte row pieces share are fetched into one L2 once (as a 2-D grid, chunk-major, the blocks of a
+    // chunk ran on different XCDs at different times: 6.1 GB read per launch for 2.4 GB of tiles)
+    const int ncb = (D + FEAT_SB - 1) / FEAT_SB;
+    const int chunk = (int)(blockIdx.x / (8 * ncb)) * 8 + (int)(blockIdx.x & 7), cb = (int)(blockIdx.x >> 3) % ncb;
+    if (chunk >= nchunks) return;
+    const int s = chunk_sess[chunk];
+    const long p0 = chunk_p0[chunk];
+    const long n = coff[s + 1] - coff[s];
+    const int64_t *ix = idx + coff[s];
+    const long dw = win / 2;
+    const long p1 = (p0 + 16 * SL < n) ? p0 + 16 * SL : n;
+    auto centre = [&](long p) { return p < dw ? dw : (p > n - dw - 1 ? n - dw - 1 : p); };
+    const long qa = centre(p0) - dw, qb = centre(p1 - 1) + dw + 1;     // rows [qa, qb) of the session's labelled frames
+    const int j0 = cb * FEAT_SB;
+    const int col = threadIdx.x & (FEAT_SB - 1), sub = threadIdx.x / FEAT_SB;
+    const bool col_ok = j0 + col < D;
+    // Stage 1: the row numbers of the tile's labelled frames, one coalesced pass into LDS.  Stage 2: the row pieces,
+    // 16 rows per step and 16 steps in flight per thread (a row number followed by its dependent row load, ~80 times
+    // in a row per thread, was most of the kernel's time with two workgroups per CU to hide it).
+    const int nrows = (int)(qb - qa);
+    int *rown = reinterpret_cast<int *>(tile + (size_t)(16 * SL + win) * FEAT_SB);
+    for (int i = threadIdx.x; i < nrows; i += 256) rown[i] = (int)ix[qa + i];
+    __syncthreads();
+    constexpr int RPS = 256 / FEAT_SB, NFL = 16;
+    for (int i0 = sub; i0 < nrows; i0 += RPS * NFL) {
+        TI v[NFL];
+#pragma unroll
+        for (int k = 0; k < NFL; ++k) {
+            const int i = i0 + k * RPS;
+            v[k] = col_ok ? Y[(long)rown[i < nrows ? i : nrows - 1] * D + j0 + col] : (TI)0;
+        }
+#pragma unroll
+        for (int k = 0; k < NFL; ++k) {
+            const int i = i0 + k * RPS;
+            if (i < nrows) tile[i * FEAT_SB + col] = v[k];
+        }
+    }
+    __syncthreads();
+    const long a = p0 + (long)sub * SL, b = (a + SL < p1) ? a + SL : p1;
+    if (a >= b || !col_ok) return;
+    const TI *tc = tile + col - qa * FEAT_SB;                // tc[q * FEAT_SB] = value of labelled frame q
+    const double w = (double)win, inv_w = 1.0 / w;
+    long c = centre(a);
+    const double pivot = (double)tc[(c - dw) * FEAT_SB];
+    double sum = 0.0, ssq = 0.0;
+#pragma unroll 8
+    for (long q = c - dw; q <= c + dw; ++q) {
+        const double v = (double)tc[q * FEAT_SB] - pivot;
+        sum += v;
+        ssq += v * v;
+    }
+    for (long p = a; p < b; ++p) {
+        const long cn = centre(p);
+        if (cn != c) {      // the window moves by one labelled frame
+            const double vin = (double)tc[(cn + dw) * FEAT_SB] - pivot;
+            const double vout = (double)tc[(c - dw) * FEAT_SB] - pivot;
+            sum += vin - vout;
+            ssq += vin * vin - vout * vout;
+            c = cn;
+        }
+        out[(compact ? coff[s] + p : ix[p]) * D + j0 + col] =
+            slide_value<TO>((double)tc[p * FEAT_SB], pivot, sum, ssq, w, inv_w, reduce);
+    }
+}
+
+template <typename TI, typename TO, int SL>
+static int feat_sliding_lds_launch(const void *Y, void *out, int compact, int D, const int64_t *idx, const int64_t *coff,
+                                   const int *chunk_sess, const int *chunk_p0, int nchunks, int win, int reduce,
+                                   hipStream_t st)
+{
+    const size_t lds = (size_t)(16 * SL + win) * FEAT_SB * sizeof(TI) + (size_t)(16 * SL + win) * sizeof(int);
+    SKM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_feat_sliding_lds<TI, TO, SL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned ncb = (unsigned)((D + FEAT_SB - 1) / FEAT_SB);
+    hipLaunchKernelGGL((k_feat_sliding_lds<TI, TO, SL>), dim3((unsigned)((nchunks + 7) / 8) * 8 * ncb), dim3(256), lds, st,
+                       (const TI *)Y, (TO *)out, compact, D, idx, coff, chunk_sess, chunk_p0, nchunks, win, reduce);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
+// positions per chunk of the LDS kernel for an input type (the host cuts the work list with it)
+extern "C" int skm_feat_sliding_lds_chunk(int in_f64) { return in_f64 ? 16 * 29 : 16 * 53; }
+
+// chunks of sessions with MORE than `win` labelled frames, chunk length skm_feat_sliding_lds_chunk(in_f64); win <= 301
+// keeps the tile inside the 160 KB of LDS
+extern "C" int skm_feat_sliding_norm_lds(void *ctx_, const void *Y, int in_f64, void *out, int out_f64, int compact, int D,
+                                         const int64_t *idx, const int64_t *coff, const int *chunk_sess,
+                                         const int *chunk_p0, int nchunks, int win, int reduce, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && D > 0 && nchunks >= 0 && win >= 3 && (win & 1) && win <= 601 && Y && out && Y != out &&
+                    (out_f64 || compact) && (in_f64 || !out_f64) && idx && coff && (nchunks == 0 || (chunk_sess && chunk_p0)),
+                "skm_feat_sliding_norm_lds: bad argument");
+    if (nchunks == 0) return SKM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    SkmProfScope ps(ctx, "k_feat_sliding", st);
+    if (in_f64 && out_f64)
+        return feat_sliding_lds_launch<double, double, 29>(Y, out, compact, D, idx, coff, chunk_sess, chunk_p0, nchunks, win, reduce, st);
+    if (in_f64)
+        return feat_sliding_lds_launch<double, float, 29>(Y, out, compact, D, idx, coff, chunk_sess, chunk_p0, nchunks, win, reduce, st);
+    return feat_sliding_lds_launch<float, float, 53>(Y, out, compact, D, idx, coff, chunk_sess, chunk_p0, nchunks, win, reduce, st);
 }
 
 extern "C" int skm_feat_sliding_norm(void *ctx_, const void *Y, const void *Yn, int in_f64, void *out, int out_f64,

@@ -73,6 +73,12 @@ SIGNATURES = {
     "skm_feat_workspace_bytes": (_c_size_t, [_c_long, _c_int, _c_int, _c_int]),
     "skm_feat_sliding_norm": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
                                        _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "skm_feat_sliding_lds_chunk": (_c_int, [_c_int]),
+    "skm_feat_sliding_norm_lds": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
+                                           _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
+    "skm_label_index_workspace_bytes": (_c_size_t, [_c_long]),
+    "skm_label_index": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
+                                 _c_size_t, _c_void_p]),
     "skm_feat_postproc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_long, _c_void_p, _c_int, _c_void_p, _c_void_p,
                                    _c_int, _c_long, _c_int, _c_int, _dp, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p,
                                    _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
@@ -472,39 +478,66 @@ class HipEngine(object):
         seg = np.asarray(seg_host, dtype=np.int64)
         if not isinstance(label, torch.Tensor):
             label = torch.from_numpy(np.ascontiguousarray(np.asarray(label, dtype=np.uint8)))
-        lab = label.to(self.device).ne(0)
+        lab = label.to(self.device)
+        if lab.dtype != torch.uint8:
+            lab = lab.ne(0).to(torch.uint8)
+        lab = lab.contiguous()
         assert lab.numel() == Y.shape[0] and seg[0] == 0 and seg[-1] <= lab.numel()
-        before = torch.zeros(lab.numel() + 1, dtype=torch.int64, device=self.device)
-        torch.cumsum(lab, dim=0, out=before[1:])
-        coff = before[self._i64_dev(seg)].cpu().numpy()
-        idx = torch.nonzero(lab[:int(seg[-1])]).reshape(-1)
+        # rows of the labelled frames and labelled frames before each session (skm_label_index); S + 1 counts come to
+        # the host to size the work lists
+        T_lab = int(seg[-1])
+        seg_dev = self._i64_dev(seg)
+        idx_dev = torch.empty(max(T_lab, 1), dtype=torch.int64, device=self.device)
+        coff_dev = torch.empty(seg.size, dtype=torch.int64, device=self.device)
+        if T_lab > 0:
+            need = self.lib.skm_label_index_workspace_bytes(T_lab)
+            iws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            self._check(self.lib.skm_label_index(self.ctx, self._ptr(lab), T_lab, self._ptr(seg_dev), seg.size - 1,
+                                                 self._ptr(idx_dev), self._ptr(coff_dev), self._ptr(iws), need, self._stream()))
+        else:
+            coff_dev.zero_()
+        coff = coff_dev.cpu().numpy()
+        idx_dev = idx_dev[:int(coff[-1])]
         n = np.diff(coff)
         short = n <= win
         if callable(Yn):
             Yn = Yn() if short.any() else None
         assert Yn is not None or not short.any()
         assert Yn is None or (Yn.dtype == Y.dtype and Yn.shape == Y.shape and Yn.is_contiguous())
-        span = n if compact else np.where(short, np.diff(seg), n)   # positions to walk per session
-        chunk_len = 512             # (win + 2 chunk_len) / chunk_len reads per output: 2.6 (4.4 at 128; 5.2 -> 4.1 ms)
-        per = (span + chunk_len - 1) // chunk_len
-        chunk_sess = np.repeat(np.arange(n.size, dtype=np.int32), per)
-        first = np.concatenate([[0], np.cumsum(per)])[:-1]
-        chunk_p0 = ((np.arange(chunk_sess.size, dtype=np.int64) - np.repeat(first, per)) * chunk_len).astype(np.int32)
         if compact:
             out = torch.empty((int(coff[-1]), Y.shape[1]), dtype=out_dtype or torch.float32, device=self.device)
             assert Y.dtype == torch.float64 or out.dtype == torch.float32
         else:
             out = Y.clone()
-        idx_dev, coff_dev, seg_dev = idx.contiguous(), self._i64_dev(coff), self._i64_dev(seg)
-        cs = torch.from_numpy(chunk_sess).to(self.device)
-        cp = torch.from_numpy(chunk_p0).to(self.device)
-        if chunk_sess.size:
-            self._check(self.lib.skm_feat_sliding_norm(self.ctx, self._ptr(Y), self._ptr(Yn),
-                                                       1 if Y.dtype == torch.float64 else 0, self._ptr(out),
-                                                       1 if out.dtype == torch.float64 else 0, 1 if compact else 0, Y.shape[1],
-                                                       self._ptr(idx_dev), self._ptr(coff_dev), self._ptr(seg_dev),
-                                                       self._ptr(cs), self._ptr(cp), int(chunk_sess.size), chunk_len, int(win),
-                                                       1 if reduce else 0, self._stream()))
+        in_f64, out_f64 = 1 if Y.dtype == torch.float64 else 0, 1 if out.dtype == torch.float64 else 0
+
+        def work_list(span, chunk_len):
+            per = (span + chunk_len - 1) // chunk_len
+            chunk_sess = np.repeat(np.arange(n.size, dtype=np.int32), per)
+            first = np.concatenate([[0], np.cumsum(per)])[:-1]
+            chunk_p0 = ((np.arange(chunk_sess.size, dtype=np.int64) - np.repeat(first, per)) * chunk_len).astype(np.int32)
+            return torch.from_numpy(chunk_sess).to(self.device), torch.from_numpy(chunk_p0).to(self.device)
+        # sessions with more than `win` labelled frames: window in LDS, every row read once per chunk (+ win rows of halo)
+        if (~short).any() and win <= 601 and os.environ.get("SKM_SLIDING_LDS", "1") != "0":
+            cs, cp = work_list(np.where(short, 0, n), self.lib.skm_feat_sliding_lds_chunk(in_f64))
+            self._check(self.lib.skm_feat_sliding_norm_lds(self.ctx, self._ptr(Y), in_f64, self._ptr(out), out_f64,
+                                                           1 if compact else 0, Y.shape[1], self._ptr(idx_dev),
+                                                           self._ptr(coff_dev), self._ptr(cs), self._ptr(cp),
+                                                           int(cs.numel()), int(win), 1 if reduce else 0, self._stream()))
+            todo = short
+        else:
+            todo = np.ones_like(short)
+        # short sessions (whole-session result copied from Yn; frames when not compact), or every session when the
+        # window does not fit the LDS: lane-per-column walk
+        span = np.where(todo, n if compact else np.where(short, np.diff(seg), n), 0)
+        if span.any():
+            chunk_len = 512
+            cs, cp = work_list(span, chunk_len)
+            self._check(self.lib.skm_feat_sliding_norm(self.ctx, self._ptr(Y), self._ptr(Yn), in_f64, self._ptr(out), out_f64,
+                                                       1 if compact else 0, Y.shape[1], self._ptr(idx_dev),
+                                                       self._ptr(coff_dev), self._ptr(seg_dev), self._ptr(cs), self._ptr(cp),
+                                                       int(cs.numel()), chunk_len, int(win), 1 if reduce else 0,
+                                                       self._stream()))
         return out, idx_dev, coff
 
     # ------------------------------------------------------------------ i-vector back-end reductions (float64)
