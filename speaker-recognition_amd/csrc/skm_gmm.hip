@@ -392,6 +392,73 @@ __device__ __forceinline__ void lane_reduce16(float (&v)[16], int c, Op op)
     v[0] = op(v[0], dpp_f32<0xB1>(v[0]));   // lane ^ 1: quad_perm [1,0,3,2]
 }
 
+// VALU diet of the single-sweep kernels (every vector instruction takes issue cycles from the SIMD's f32 MFMA stream).
+// fmaxf() on operands the compiler cannot prove quiet (asm MFMA results) costs a canonicalising v_max_f32 v, v, v per
+// operand; the hardware maximum needs none, and v_max3 takes three operands.
+__device__ __forceinline__ float vmax2(float a, float b)
+{
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c)
+{
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+struct OpMaxHw {
+    __device__ __forceinline__ float operator()(float a, float b) const { return vmax2(a, b); }
+};
+
+// m[r] = max over the wave's NCT component tiles of lg[ct][r]
+template <int NCT>
+__device__ __forceinline__ void tile_row_max(const f32x16 (&lg)[NCT], float (&m)[16])
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if constexpr (NCT == 1)
+            m[r] = lg[0][r];
+        else if constexpr (NCT == 2)
+            m[r] = vmax2(lg[0][r], lg[1][r]);
+        else if constexpr (NCT == 4)
+            m[r] = vmax2(vmax3(lg[0][r], lg[1][r], lg[2][r]), lg[3][r]);
+        else {
+            m[r] = lg[0][r];
+#pragma unroll
+            for (int ct = 1; ct < NCT; ++ct) m[r] = vmax2(m[r], lg[ct][r]);
+        }
+    }
+}
+
+// lg <- 2^(lg - max of the row), sm[r] = sum over the tiles; rmax = ls + 4 h holds the row maxima of this half-wave's
+// 16 rows in groups of four (stride 8).  Two rows at a time: the subtraction and the sum are packed (v_pk_add_f32).
+template <int NCT>
+__device__ __forceinline__ void tile_exp_sum(f32x16 (&lg)[NCT], const float *rmax, float (&sm)[16])
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 m4 = *reinterpret_cast<const f32x4 *>(rmax + 8 * q4);
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            const f32x2 mm = {m4[i], m4[i + 1]};
+            f32x2 acc = {0.f, 0.f};
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const f32x2 l = {lg[ct][4 * q4 + i], lg[ct][4 * q4 + i + 1]};
+                const f32x2 d = l - mm;
+                const f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                lg[ct][4 * q4 + i] = e[0];
+                lg[ct][4 * q4 + i + 1] = e[1];
+                acc += e;
+            }
+            sm[4 * q4 + i] = acc[0];
+            sm[4 * q4 + i + 1] = acc[1];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // sweep 1: per (component block, frame) partial max / sum of exp2
 // ------------------------------------------------------------------------------------------------
@@ -502,13 +569,8 @@ __global__ __launch_bounds__(512, 2) void k_lse_partial(LseArgs a)
         // Row (= frame) maximum and sum of 2^(l - max) over this block's NCT * 32 components: exact maximum
         // first (DPP butterfly), broadcast through the wave's LDS row, one exponential per logit.
         float m[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            m[r] = lg[0][r];
-#pragma unroll
-            for (int ct = 1; ct < NCT; ++ct) m[r] = __builtin_fmaxf(m[r], lg[ct][r]);
-        }
-        lane_reduce16(m, c, OpMax());
+        tile_row_max<NCT>(lg, m);
+        lane_reduce16(m, c, OpMaxHw());
         const int frame = acc_row((c >> 1) & 15, h);
         float *mrow = xs + 32 * g.XS;   // 32 floats behind the wave's tile
         if ((c & 1) == 0) mrow[frame] = m[0];
@@ -918,34 +980,15 @@ __global__ __launch_bounds__(512, 2) void k_estep_fused(FusedArgs a)
         SKM_STAMP(1);
         // exact per-frame maximum over this wave's components ...
         float m[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            m[r] = lg[0][r];
-#pragma unroll
-            for (int ct = 1; ct < NCT; ++ct) m[r] = __builtin_fmaxf(m[r], lg[ct][r]);
-        }
-        lane_reduce16(m, c, OpMax());
+        tile_row_max<NCT>(lg, m);
+        lane_reduce16(m, c, OpMaxHw());
         const int frame = acc_row((c >> 1) & 15, h);
         if ((c & 1) == 0) ls[frame] = m[0];
         wave_lds_fence();
         // ... e = 2^(l - max) replaces the logits (each exponential is taken once; gamma = e * factor later),
         // and the wave's per-frame sum of e
         float sm[16];
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float acc1 = 0.f;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    const float e = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + i] - m4[i]);
-                    lg[ct][4 * q4 + i] = e;
-                    acc1 += e;
-                }
-                sm[4 * q4 + i] = acc1;
-            }
-        }
+        tile_exp_sum<NCT>(lg, ls + 4 * h, sm);
         lane_reduce16(sm, c, OpAdd());
         if ((c & 1) == 0) {
             partm[(pslot * NWV + wave) * 32 + frame] = m[0];
@@ -1517,32 +1560,13 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
 
         // exact per-frame maximum over this wave's NCT*32 components, e = 2^(l - max), per-frame sum of e
         float m[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            m[r] = lg[0][r];
-#pragma unroll
-            for (int ct = 1; ct < NCT; ++ct) m[r] = __builtin_fmaxf(m[r], lg[ct][r]);
-        }
-        lane_reduce16(m, c, OpMax());
+        tile_row_max<NCT>(lg, m);
+        lane_reduce16(m, c, OpMaxHw());
         const int frame = acc_row((c >> 1) & 15, h);
         if ((c & 1) == 0) ls[frame] = m[0];
         wave_lds_fence();
         float sm[16];
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float acc1 = 0.f;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    const float e = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + i] - m4[i]);
-                    lg[ct][4 * q4 + i] = e;
-                    acc1 += e;
-                }
-                sm[4 * q4 + i] = acc1;
-            }
-        }
+        tile_exp_sum<NCT>(lg, ls + 4 * h, sm);
         lane_reduce16(sm, c, OpAdd());
         if ((c & 1) == 0) {
             partm[(pslot * NWV + wave) * 32 + frame] = m[0];
@@ -1709,31 +1733,12 @@ __global__ __launch_bounds__(64, NCT == 1 ? 2 : 1) void k_estep_solo(FusedArgs a
 
         // exact per-frame maximum over all components, e = 2^(l - max), per-frame sum of e
         float m[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            m[r] = lg[0][r];
-#pragma unroll
-            for (int ct = 1; ct < NCT; ++ct) m[r] = __builtin_fmaxf(m[r], lg[ct][r]);
-        }
-        lane_reduce16(m, c, OpMax());
+        tile_row_max<NCT>(lg, m);
+        lane_reduce16(m, c, OpMaxHw());
         if ((c & 1) == 0) ls[frame] = m[0];
         wave_lds_fence();
         float sm[16];
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float acc1 = 0.f;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    const float e = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + i] - m4[i]);
-                    lg[ct][4 * q4 + i] = e;
-                    acc1 += e;
-                }
-                sm[4 * q4 + i] = acc1;
-            }
-        }
+        tile_exp_sum<NCT>(lg, ls + 4 * h, sm);
         lane_reduce16(sm, c, OpAdd());
         if ((c & 1) == 0) {
             const bool valid = frame < nvalid;
@@ -2088,32 +2093,13 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
 
             // exact per-frame maximum over this wave's 128 components, e = 2^(l - max), per-frame sum of e
             float m[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                m[r] = lg[0][r];
-#pragma unroll
-                for (int ct = 1; ct < NCT; ++ct) m[r] = __builtin_fmaxf(m[r], lg[ct][r]);
-            }
-            lane_reduce16(m, c, OpMax());
+            tile_row_max<NCT>(lg, m);
+            lane_reduce16(m, c, OpMaxHw());
             const int frame = acc_row((c >> 1) & 15, h);
             if ((c & 1) == 0) ls[frame] = m[0];
             wave_lds_fence();
             float sm[16];
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float acc1 = 0.f;
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) {
-                        const float e = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + i] - m4[i]);
-                        lg[ct][4 * q4 + i] = e;
-                        acc1 += e;
-                    }
-                    sm[4 * q4 + i] = acc1;
-                }
-            }
+            tile_exp_sum<NCT>(lg, ls + 4 * h, sm);
             lane_reduce16(sm, c, OpAdd());
             // publish this wave's row of partials, then its flag
             if ((c & 1) == 0) {
@@ -2372,13 +2358,8 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
 
             // exact per-frame maximum over this wave's 128 components, e = 2^(l - max), per-frame sum of e
             float m[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                m[r] = lg[0][r];
-#pragma unroll
-                for (int ct = 1; ct < NCT; ++ct) m[r] = __builtin_fmaxf(m[r], lg[ct][r]);
-            }
-            lane_reduce16(m, c, OpMax());
+            tile_row_max<NCT>(lg, m);
+            lane_reduce16(m, c, OpMaxHw());
             const int frame = acc_row((c >> 1) & 15, h);
             if ((c & 1) == 0) ls[frame] = m[0];
             wave_lds_fence();
