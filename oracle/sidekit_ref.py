@@ -739,3 +739,35 @@ def plda_train(modelset, x, rank_f, nb_iter=10, scaling_factor=1.0):
         Sigma = sigma_obs - F.dot(_C) / session_per_model.sum()      # :900
         F = F.dot(scipy.linalg.cholesky(_R))                         # :903
     return mean, F, Sigma
+
+
+def full_plda_scores(enroll_iv, test_iv, mu, F, G, Sigma, p_known=0.0, scaling_factor=1.0):
+    """full_PLDA_scoring (sidekit/iv_scoring.py:266-361) on aligned i-vectors: rows of enroll_iv are the models, rows of
+    test_iv the segments of the score matrix."""
+    e = np.asarray(enroll_iv, dtype=np.float64) - mu
+    t = np.asarray(test_iv, dtype=np.float64) - mu
+    invSigma = scipy.linalg.inv(Sigma)
+    A = np.linalg.inv(G.T.dot(invSigma * scaling_factor).dot(G) + np.eye(G.shape[1]))
+    B = F.T.dot(invSigma * scaling_factor).dot(np.eye(mu.shape[0]) - G.dot(A).dot(G.T).dot(invSigma * scaling_factor))
+    K = B.dot(F)
+    K1 = scipy.linalg.inv(K + np.eye(F.shape[1]))
+    K2 = scipy.linalg.inv(2 * K + np.eye(F.shape[1]))
+    constant = np.linalg.slogdet(K2)[1] / 2.0 - np.linalg.slogdet(K1)[1]
+    tt, et = B.dot(t.T), B.dot(e.T)
+    S1 = np.array([tt[:, i].dot(K1).dot(tt[:, i]) / 2. for i in range(tt.shape[1])])
+    score = np.zeros((et.shape[1], tt.shape[1]))
+    S2 = np.zeros(et.shape[1])
+    for m in range(et.shape[1]):
+        both = tt + et[:, m:m + 1]
+        S2[m] = et[:, m].dot(K1).dot(et[:, m]) / 2.
+        score[m] = np.einsum("ij, ji->i", both.T.dot(K2), both) / 2.
+    score += constant - (S1 + S2[:, None])
+    score *= scaling_factor
+    if p_known != 0:
+        N = score.shape[0]
+        ex = np.exp(score)
+        out = np.empty(score.shape)
+        for ii in range(N):
+            out[ii] = score[ii] - np.log(p_known * ex[~(np.arange(N) == ii)].sum(axis=0) / (N - 1) + (1 - p_known))
+        score = out
+    return score

@@ -10,7 +10,7 @@ from .factor_analyser import FactorAnalyser  # noqa: F401
 from .gmm_scoring import gmm_scoring, gmm_scoring_singleThread  # noqa: F401
 from . import iv_scoring  # noqa: F401
 from .iv_scoring import (cosine_scoring, mahalanobis_scoring, two_covariance_scoring, fast_PLDA_scoring,  # noqa: F401
-                         PLDA_scoring)
+                         PLDA_scoring, full_PLDA_scoring)
 from . import dist  # noqa: F401
 
 PARAM_TYPE = "float32"

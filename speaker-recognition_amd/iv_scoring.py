@@ -164,9 +164,44 @@ def fast_PLDA_scoring(enroll, test, ndx, mu, F, Sigma, test_uncertainty=None, Vt
     return _finish(s, clean_ndx)
 
 
+def full_PLDA_scoring(enroll, test, ndx, mu, F, G, Sigma, p_known=0.0, scaling_factor=1., check_missing=True):
+    """PLDA log-likelihood ratios with a within-class subspace G (iv_scoring.py:266-361): i-vectors projected by
+    B = F'S(I - G A G'S), S = scaling * inv(Sigma), then 0.5 (e+t)'K2(e+t) - 0.5 t'K1 t - 0.5 e'K1 e + constant for every
+    pair.  The R x R / rank x rank inverses are host LAPACK as in the reference; the projections are two device GEMMs
+    and the pair terms e'K2 t + 0.5 e'(K2-K1)e + 0.5 t'(K2-K1)t the same primitives as the other scorers.  Like the
+    reference, repeated enrolment models are NOT averaged here (:285-288 are commented out there)."""
+    import scipy.linalg
+    enroll_copy = copy.deepcopy(enroll)
+    test_copy = copy.deepcopy(test)
+    clean_ndx = _check_missing_model(enroll_copy, test_copy, ndx) if check_missing else ndx
+    invSigma = scipy.linalg.inv(Sigma)
+    I_iv = np.eye(mu.shape[0], dtype='float')
+    I_ch = np.eye(G.shape[1], dtype='float')
+    I_spk = np.eye(F.shape[1], dtype='float')
+    A = np.linalg.inv(G.T.dot(invSigma * scaling_factor).dot(G) + I_ch)
+    B = F.T.dot(invSigma * scaling_factor).dot(I_iv - G.dot(A).dot(G.T).dot(invSigma * scaling_factor))
+    K = B.dot(F)
+    K1 = scipy.linalg.inv(K + I_spk)
+    K2 = scipy.linalg.inv(2 * K + I_spk)
+    constant = np.linalg.slogdet(K2)[1] / 2.0 - np.linalg.slogdet(K1)[1]
+
+    eng = enroll.engine
+    mu_dev = eng._f64_dev(np.asarray(mu, dtype=np.float64).reshape(1, -1))
+    Bt = eng._f64_dev(np.ascontiguousarray(B.T))
+    Ep = eng.gemm(eng.rows_center(eng._f64_dev(enroll_copy.stat1), Mu=mu_dev), Bt)      # rows = B (e - mu)
+    Tp = eng.gemm(eng.rows_center(eng._f64_dev(test_copy.stat1), Mu=mu_dev), Bt)
+    s = eng.to_host(_pair_scores(eng, Ep, Tp, K2, K2 - K1, 0.5, 0.5, 0.5))
+    s = (s + constant) * scaling_factor
+    if p_known != 0:
+        N = s.shape[0]
+        ex = np.exp(s)
+        s = s - np.log(p_known * (ex.sum(axis=0)[None, :] - ex) / (N - 1) + (1 - p_known))
+    return _finish(s, clean_ndx)
+
+
 def PLDA_scoring(enroll, test, ndx, mu, F, G, Sigma, test_uncertainty=None, Vtrans=None, p_known=0.0,
                  scaling_factor=1., full_model=False):
-    """iv_scoring.py:208-263; only the simplified model (G unused) is on this path."""
+    """iv_scoring.py:208-263."""
     assert isinstance(enroll, StatServer), 'First parameter should be a StatServer'
     assert isinstance(test, StatServer), 'Second parameter should be a StatServer'
     assert isinstance(ndx, Ndx), 'Third parameter should be an Ndx'
@@ -174,6 +209,6 @@ def PLDA_scoring(enroll, test, ndx, mu, F, G, Sigma, test_uncertainty=None, Vtra
     assert enroll.stat1.shape[1] == F.shape[0], 'I-vectors and co-variance matrix dimension mismatch'
     assert enroll.stat1.shape[1] == G.shape[0], 'I-vectors and co-variance matrix dimension mismatch'
     if full_model:
-        raise NotImplementedError('full_PLDA_scoring (within-class factor G) is not on this path')
+        return full_PLDA_scoring(enroll, test, ndx, mu, F, G, Sigma, p_known=p_known, scaling_factor=scaling_factor)
     return fast_PLDA_scoring(enroll, test, ndx, mu, F, Sigma, test_uncertainty, Vtrans, p_known=p_known,
                              scaling_factor=scaling_factor, check_missing=True)

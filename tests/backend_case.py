@@ -82,3 +82,28 @@ def run_backend_case(sk, eng, rtol=1e-10):
     enroll, test, ndx = trial_sets()
     sc = sk.PLDA_scoring(enroll, test, ndx, g["plda_mu"], g["plda_F"], np.zeros((int(g["R"]), 1)), g["plda_Sigma"])
     _close(sc.scoremat, g["plda_closed_scoremat"], 10 * rtol)
+
+
+def run_full_plda_case(sk, eng, rtol=1e-9):
+    """full_PLDA_scoring (iv_scoring.py:266-361) against the real reference (tests/golden/full_plda.npz, tools/gen_golden.py
+    gen_full_plda): closed set, open set, a scaling factor, the PLDA_scoring(full_model=True) dispatch."""
+    g = np.load(os.path.join(GOLD, "full_plda.npz"), allow_pickle=False)
+
+    def trial_sets():
+        enroll = _server(sk, eng, g["enroll_modelset"], g["enroll_segset"], g["enroll_iv"])
+        test = _server(sk, eng, g["test_segset"], g["test_segset"], g["test_iv"])
+        ndx = sk.Ndx()
+        ndx.modelset, ndx.segset, ndx.trialmask = g["ndx_modelset"], g["ndx_segset"], g["trialmask"]
+        return enroll, test, ndx
+    for tag, kw in (("closed", dict()), ("open", dict(p_known=0.4)), ("scaled", dict(p_known=0.2, scaling_factor=0.7))):
+        enroll, test, ndx = trial_sets()
+        e0, t0 = enroll.stat1.copy(), test.stat1.copy()
+        sc = sk.full_PLDA_scoring(enroll, test, ndx, g["mu"], g["F"], g["G"], g["Sigma"], **kw)
+        assert list(sc.modelset) == list(g["modelset"]) and list(sc.segset) == list(g["segset"])
+        np.testing.assert_array_equal(sc.scoremask, g["scoremask"])
+        _close(sc.scoremat, g["full_%s_scoremat" % tag], rtol)
+        np.testing.assert_array_equal(enroll.stat1, e0)           # works on copies, like the reference
+        np.testing.assert_array_equal(test.stat1, t0)
+    enroll, test, ndx = trial_sets()
+    sc = sk.PLDA_scoring(enroll, test, ndx, g["mu"], g["F"], g["G"], g["Sigma"], p_known=0.4, full_model=True)
+    _close(sc.scoremat, g["full_open_scoremat"], rtol)

@@ -10,7 +10,7 @@ import pytest
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import sidekit_ref as orc  # noqa: E402
-from backend_case import run_backend_case, _server, _close  # noqa: E402
+from backend_case import run_backend_case, run_full_plda_case, _server, _close  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -28,6 +28,10 @@ def eng(sk):
 
 def test_backend_vs_reference_golden(sk, eng):
     run_backend_case(sk, eng)
+
+
+def test_full_plda_scoring_vs_reference_golden(sk, eng):
+    run_full_plda_case(sk, eng)
 
 
 def test_plda_training_vs_reference_golden(sk, eng, tmp_path):

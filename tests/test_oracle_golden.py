@@ -275,6 +275,21 @@ def test_iv_backend_host_logic_vs_reference_golden():
     run_backend_case(sk, OracleEngine())
 
 
+def test_full_plda_scoring_oracle_and_host_logic_vs_reference_golden():
+    """oracle/sidekit_ref.full_plda_scores on the aligned trial sets, and the drop-in full_PLDA_scoring (Ndx filtering,
+    alignment, host inverses) on the oracle-backed engine, against the real reference."""
+    import sidekit_amd as sk
+    from fake_engine import OracleEngine
+    from backend_case import run_full_plda_case
+    g = golden("full_plda.npz")
+    e = np.array([g["enroll_iv"][list(g["enroll_modelset"]).index(m)] for m in g["modelset"]])
+    t = np.array([g["test_iv"][list(g["test_segset"]).index(sg)] for sg in g["segset"]])
+    for tag, kw in (("closed", dict()), ("open", dict(p_known=0.4)), ("scaled", dict(p_known=0.2, scaling_factor=0.7))):
+        s = orc.full_plda_scores(e, t, g["mu"], g["F"], g["G"], g["Sigma"], **kw)
+        assert np.abs(s - g["full_%s_scoremat" % tag]).max() <= 1e-12 * np.abs(g["full_%s_scoremat" % tag]).max()
+    run_full_plda_case(sk, OracleEngine())
+
+
 def test_plda_training_oracle_vs_reference_golden():
     """oracle/sidekit_ref.plda_train against the real reference's FactorAnalyser.plda (3 iterations, 1 iteration, a
     scaling factor)."""

@@ -650,6 +650,49 @@ def gen_plda(sidekit, tmp):
     print("plda", ss.stat1.shape, out["F_it3"].shape, float(np.abs(out["Sigma_it3"]).max()))
 
 
+def gen_full_plda(sidekit):
+    """full_PLDA_scoring (iv_scoring.py:266-361) and its dispatch through PLDA_scoring(full_model=True): closed set, open
+    set, a scaling factor; an Ndx naming an unknown model and an unknown segment."""
+    rs = np.random.RandomState(77)
+    R, rank_f, rank_g = 12, 5, 4
+
+    def server(modelset, segset, stat1):
+        ss = sidekit.StatServer()
+        ss.modelset = np.array(modelset)
+        ss.segset = np.array(segset)
+        ss.start = np.empty(len(segset), "|O")
+        ss.stop = np.empty(len(segset), "|O")
+        ss.stat0 = np.ones((len(segset), 1))
+        ss.stat1 = np.array(stat1, dtype=np.float64)
+        return ss
+
+    F = 0.9 * rs.randn(R, rank_f)
+    G = 0.5 * rs.randn(R, rank_g)
+    A = rs.randn(R, 3 * R)
+    Sigma = A.dot(A.T) / (3 * R) + 0.3 * np.eye(R)
+    mu = 0.4 * rs.randn(R)
+    e_models = ["m%02d" % k for k in range(7)]
+    enroll = server(e_models, ["e%d" % i for i in range(7)], F.dot(rs.randn(rank_f, 7)).T + 0.5 * rs.randn(7, R) + mu)
+    test = server(["t%d" % i for i in range(9)], ["t%d" % i for i in range(9)],
+                  F.dot(rs.randn(rank_f, 9)).T + 0.6 * rs.randn(9, R) + mu)
+    ndx = sidekit.Ndx()
+    ndx.modelset = np.array(["m05", "m01", "mXX", "m00", "m06", "m03"])
+    ndx.segset = np.array(["t7", "t3", "tY", "t0", "t1", "t5", "t8"])
+    ndx.trialmask = rs.rand(6, 7) < 0.7
+    out = dict(F=F, G=G, Sigma=Sigma, mu=mu, enroll_modelset=enroll.modelset, enroll_segset=enroll.segset,
+               enroll_iv=enroll.stat1.copy(), test_segset=test.segset, test_iv=test.stat1.copy(),
+               ndx_modelset=ndx.modelset, ndx_segset=ndx.segset, trialmask=ndx.trialmask)
+    for tag, kw in (("closed", dict()), ("open", dict(p_known=0.4)), ("scaled", dict(p_known=0.2, scaling_factor=0.7))):
+        sc = sidekit.iv_scoring.full_PLDA_scoring(copy.deepcopy(enroll), copy.deepcopy(test), ndx, mu, F, G, Sigma, **kw)
+        out["full_%s_scoremat" % tag] = sc.scoremat
+    sc2 = sidekit.iv_scoring.PLDA_scoring(copy.deepcopy(enroll), copy.deepcopy(test), ndx, mu, F, G, Sigma, p_known=0.4,
+                                          full_model=True)
+    assert np.array_equal(sc2.scoremat, out["full_open_scoremat"])
+    out.update(modelset=sc.modelset, segset=sc.segset, scoremask=sc.scoremask)
+    np.savez_compressed(os.path.join(OUT, "full_plda.npz"), **out)
+    print("full_plda", sc.scoremat.shape, list(sc.modelset))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "round2":
@@ -657,6 +700,9 @@ def main():
         gen_em_split_vad(sidekit)
         with tempfile.TemporaryDirectory() as tmp:
             gen_tv_big(sidekit, tmp)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "full_plda":
+        gen_full_plda(import_reference())
         return
     if len(sys.argv) > 1 and sys.argv[1] == "plda":
         with tempfile.TemporaryDirectory() as tmp:
@@ -695,6 +741,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         gen_tv_big(sidekit, tmp)
         gen_plda(sidekit, tmp)
+    gen_full_plda(sidekit)
 
 
 if __name__ == "__main__":
