@@ -12,6 +12,7 @@ from . import iv_scoring  # noqa: F401
 from .iv_scoring import (cosine_scoring, mahalanobis_scoring, two_covariance_scoring, fast_PLDA_scoring,  # noqa: F401
                          PLDA_scoring, full_PLDA_scoring)
 from . import dist  # noqa: F401
+from . import h5lite  # noqa: F401
 
 PARAM_TYPE = "float32"
 STAT_TYPE = "float64"

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import dist
 from . import engine as _engine
-from .mixture import Mixture, _has_h5py
+from .mixture import Mixture, _has_h5py, _h5
 from .statserver import StatServer, STAT_TYPE
 
 
@@ -79,7 +79,7 @@ class FactorAnalyser(object):
                 data[key] = np.asarray(v)
         data["fa/kind"] = kind
         if output_file_name.endswith((".h5", ".hdf5")):
-            import h5py
+            h5py = _h5()
             with h5py.File(output_file_name, "w") as fh:
                 for k, v in data.items():
                     fh.create_dataset(k, data=v, compression="gzip", fletcher32=True)
@@ -91,7 +91,7 @@ class FactorAnalyser(object):
     def read(input_filename):
         fa = FactorAnalyser()
         if input_filename.endswith((".h5", ".hdf5")):
-            import h5py
+            h5py = _h5()
             with h5py.File(input_filename, "r") as fh:
                 kind = np.asarray(fh["fa/kind"][()])
                 for i, (attr, key) in enumerate(FactorAnalyser._KEYS):

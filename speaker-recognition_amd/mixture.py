@@ -113,14 +113,14 @@ class Mixture(object):
     _FIELDS = ("w", "mu", "invcov", "invchol", "cov_var_ctl", "cst", "det")
 
     def write(self, mixture_file_name, prefix='', mode='w'):
-        """Same dataset names as mixture.py:325-359.  `.h5` needs h5py, anything else is an .npz."""
+        """Same dataset names as mixture.py:325-359.  `.h5` goes through h5py or libhdf5 (_h5), anything else is an .npz."""
         d = os.path.dirname(mixture_file_name)
         if d and not os.path.exists(d):
             os.makedirs(d)
         data = {prefix + k: np.asarray(getattr(self, k), dtype="d") for k in self._FIELDS}
         data[prefix + "a"] = np.asarray(self.A, dtype="d")
         if mixture_file_name.endswith((".h5", ".hdf5")):
-            import h5py  # raises if the GPU box has no h5py: use .npz there
+            h5py = _h5()
             with h5py.File(mixture_file_name, mode) as f:
                 for k, v in data.items():
                     f.create_dataset(k, v.shape, "d", v, compression="gzip", fletcher32=True)
@@ -130,7 +130,7 @@ class Mixture(object):
 
     def read(self, mixture_file_name, prefix=''):
         if mixture_file_name.endswith((".h5", ".hdf5")):
-            import h5py
+            h5py = _h5()
             with h5py.File(mixture_file_name, 'r') as f:
                 get = lambda k: np.asarray(f[prefix + k][()])
                 vals = {k: get(k) for k in self._FIELDS + ("a",)}
@@ -461,9 +461,23 @@ class _DeviceEM(object):
         m._compute_all()
 
 
-def _has_h5py():
+def _h5():
+    """The HDF5 module of this process: h5py when it is installed, else the same calls on libhdf5 through ctypes
+    (h5lite).  Raises ImportError when neither exists: use .npz file names there."""
     try:
-        import h5py  # noqa: F401
+        import h5py
+        return h5py
+    except ImportError:
+        from . import h5lite
+        if not h5lite.available():
+            raise ImportError("neither h5py nor libhdf5 is available: use .npz file names")
+        return h5lite
+
+
+def _has_h5py():
+    """True when .h5 products can be written and read (h5py, or libhdf5 through h5lite)."""
+    try:
+        _h5()
         return True
     except ImportError:
         return False

@@ -17,7 +17,7 @@ import numpy as np
 from . import dist
 from . import engine as _engine
 from .idmap import IdMap
-from .mixture import Mixture
+from .mixture import Mixture, _h5
 
 STAT_TYPE = np.float64
 
@@ -109,7 +109,7 @@ class StatServer(object):
                 prefix + "stat1": self.stat1.astype(np.float32),
                 prefix + "start": start, prefix + "stop": stop}
         if output_file_name.endswith((".h5", ".hdf5")):
-            import h5py
+            h5py = _h5()
             with h5py.File(output_file_name, mode) as f:
                 for k, v in data.items():
                     f.create_dataset(k, data=v, maxshape=(None,) + v.shape[1:], compression="gzip",
@@ -122,7 +122,7 @@ class StatServer(object):
     def _load_arrays(statserver_file_name, prefix=''):
         keys = ("modelset", "segset", "start", "stop", "stat0", "stat1")
         if statserver_file_name.endswith((".h5", ".hdf5")):
-            import h5py
+            h5py = _h5()
             with h5py.File(statserver_file_name, "r") as f:
                 return {k: np.asarray(f[prefix + k][()]) for k in keys}
         z = np.load(statserver_file_name, allow_pickle=False)

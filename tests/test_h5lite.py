@@ -1,0 +1,125 @@
+"""HDF5 file products without h5py (speaker-recognition_amd/h5lite.py: libhdf5 through ctypes): the reference's on-disk
+layouts -- Mixture (mixture.py:325-359), StatServer (statserver.py:418-476, float32 statistics, byte-string ids, -1 for
+missing start / stop), FactorAnalyser (factor_analyser.py:264-324, fa/* group with the kind vector) -- written and read
+back through the drop-in classes, and the raw API on the types they use.  h5py is not installed here, so these files are
+checked against what the HDF5 library itself reports, not against h5py ("parity unpinned" for h5py-written files)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sidekit_amd as sk  # noqa: E402
+h5lite = sk.h5lite
+
+pytestmark = pytest.mark.skipif(not h5lite.available(), reason="libhdf5 not found")
+
+
+def test_raw_api_round_trip(tmp_path):
+    fn = str(tmp_path / "raw.h5")
+    rs = np.random.RandomState(0)
+    data = {"f8": rs.randn(7, 5), "f4": rs.randn(300, 40).astype(np.float32), "i8": np.arange(-3, 9, dtype=np.int64),
+            "i2": np.array([0, 1, 1, 0, 1], dtype=np.int16), "names": np.array(["spk1", "a", "longer-name"]).astype("S"),
+            "grp/sub/x": rs.randn(4), "empty": np.zeros((0,)), "scalar": np.float64(3.5)}
+    with h5lite.File(fn, "w") as f:
+        for k, v in data.items():
+            kw = dict(compression="gzip", fletcher32=True) if np.ndim(v) else {}
+            f.create_dataset(k, data=v, **kw)
+        f.create_dataset("growable", data=data["f4"], maxshape=(None, 40), compression="gzip", fletcher32=True)
+        f.create_dataset("positional", (7, 5), "d", data["f8"], compression="gzip", fletcher32=True)   # mixture.py's call form
+    assert open(fn, "rb").read(8) == b"\x89HDF\r\n\x1a\n"
+    with h5lite.File(fn, "r") as f:
+        assert sorted(f.keys()) == sorted(["f8", "f4", "i8", "i2", "names", "grp", "empty", "scalar", "growable", "positional"])
+        assert "grp/sub/x" in f and "grp/sub" in f and "grp/nope" not in f and f.get("missing") is None
+        for k, v in data.items():
+            got = f[k][()]
+            assert got.dtype == np.asarray(v).dtype and got.shape == np.shape(v)
+            np.testing.assert_array_equal(got, v)
+        assert f["f4"].shape == (300, 40) and f["f4"].dtype == np.float32 and len(f["f4"]) == 300
+        np.testing.assert_array_equal(f["f8"][2:5, 1], data["f8"][2:5, 1])
+        np.testing.assert_array_equal(f.get("growable").value, data["f4"])
+        np.testing.assert_array_equal(f["positional"][()], data["f8"])
+        with pytest.raises(KeyError):
+            f["missing"]
+    with h5lite.File(fn, "a") as f:                       # append mode keeps what is there
+        f.create_dataset("later", data=np.ones(3))
+    with h5lite.File(fn, "r") as f:
+        assert "later" in f and "f8" in f
+
+
+def test_checksum_detects_corruption(tmp_path):
+    fn = str(tmp_path / "c.h5")
+    a = np.arange(50000, dtype=np.float64)
+    with h5lite.File(fn, "w") as f:
+        f.create_dataset("x", data=a, fletcher32=True)     # chunked, checksum only: the bytes are findable
+    raw = bytearray(open(fn, "rb").read())
+    pos = bytes(raw).find(a[1000:1004].tobytes())
+    assert pos > 0
+    raw[pos + 3] ^= 0x40
+    open(fn, "wb").write(bytes(raw))
+    with h5lite.File(fn, "r") as f:
+        with pytest.raises(IOError):
+            f["x"][()]
+
+
+def test_mixture_statserver_factor_analyser_h5_products(tmp_path):
+    rs = np.random.RandomState(3)
+    C, D = 6, 5
+    m = sk.Mixture()
+    m.w = rs.dirichlet(np.ones(C))
+    m.mu = rs.randn(C, D)
+    m.invcov = rs.uniform(0.5, 2.0, size=(C, D))
+    m.cov_var_ctl = 1.0 / m.invcov
+    m._compute_all()
+    fn = str(tmp_path / "ubm.h5")
+    m.write(fn)
+    back = sk.Mixture()
+    back.read(fn)
+    for k in ("w", "mu", "invcov", "cov_var_ctl", "cst", "det", "A"):
+        np.testing.assert_array_equal(getattr(back, k), getattr(m, k))
+    assert back.validate()
+    with h5lite.File(fn, "r") as f:                        # dataset names and types of mixture.py:334-358
+        assert sorted(f.keys()) == sorted(["w", "mu", "invcov", "invchol", "cov_var_ctl", "cst", "det", "a"])
+        assert all(f[k].dtype == np.float64 for k in f.keys())
+
+    S = 9
+    ss = sk.StatServer()
+    ss.modelset = np.array(["m%d" % (i % 4) for i in range(S)])
+    ss.segset = np.array(["seg-%02d" % i for i in range(S)])
+    ss.start = np.empty(S, "|O")
+    ss.stop = np.empty(S, "|O")
+    ss.start[2], ss.stop[2] = 10, 250
+    ss.stat0 = rs.uniform(0, 30, size=(S, C))
+    ss.stat1 = rs.randn(S, C * D) * 7
+    fs = str(tmp_path / "stats.h5")
+    ss.write(fs)
+    rd = sk.StatServer.read(fs)
+    assert list(rd.modelset) == list(ss.modelset) and list(rd.segset) == list(ss.segset)
+    assert rd.start[2] == 10 and rd.stop[2] == 250 and rd.start[0] is None and rd.stop[5] is None
+    np.testing.assert_array_equal(rd.stat0, ss.stat0.astype(np.float32).astype(np.float64))     # the float32 storage contract
+    np.testing.assert_array_equal(rd.stat1, ss.stat1.astype(np.float32).astype(np.float64))
+    sub = sk.StatServer.read_subset(fs, np.array([7, 1, 4]))
+    assert list(sub.segset) == ["seg-07", "seg-01", "seg-04"]
+    np.testing.assert_array_equal(sub.stat1, rd.stat1[[7, 1, 4]])
+    with h5lite.File(fs, "r") as f:
+        assert f["stat0"].dtype == np.float32 and f["stat1"].dtype == np.float32 and f["modelset"].dtype.kind == "S"
+    ss.write(fs, prefix="second/")                         # a second StatServer under a prefix (statserver.py:418-449)
+    with h5lite.File(fs, "r") as f:
+        assert "second/stat1" in f and "stat1" not in f    # mode 'w' starts a new file, as h5py does
+    rd2 = sk.StatServer.read(fs, prefix="second/")
+    np.testing.assert_array_equal(rd2.stat0, rd.stat0)
+
+    fa = sk.FactorAnalyser()
+    fa.mean = rs.randn(C * D)
+    fa.F = rs.randn(C * D, 4)
+    fa.Sigma = rs.uniform(0.5, 2.0, size=C * D)
+    ff = str(tmp_path / "tv.h5")
+    fa.write(ff)
+    fb = sk.FactorAnalyser.read(ff)
+    np.testing.assert_array_equal(fb.F, fa.F)
+    np.testing.assert_array_equal(fb.mean, fa.mean)
+    np.testing.assert_array_equal(fb.Sigma, fa.Sigma)
+    assert fb.G is None and fb.H is None
+    with h5lite.File(ff, "r") as f:                        # fa/* layout and the kind vector of factor_analyser.py:264-290
+        assert f.keys() == ["fa"] and list(f["fa/kind"][()]) == [1, 1, 0, 0, 1]
