@@ -7,7 +7,7 @@ by a real SIDEKIT are read through the same calls h5py would make.
 
 Covered: File(name, "r" | "w" | "a" | "r+"), context manager, close(); create_dataset(name, shape=None, dtype=None,
 data=None, maxshape=None, compression=None | "gzip", fletcher32=False); f[name] -> Dataset with .shape, .dtype, [()],
-[index], .value; f.get(name); name in f; keys().  Types: float32 / float64, (u)int8..64, fixed-length byte strings.
+[index], .value, .resize(shape), dset[n:] = rows; f.get(name); name in f; keys().  Types: float32 / float64, (u)int8..64, fixed-length byte strings.
 """
 import ctypes
 import ctypes.util
@@ -85,6 +85,9 @@ def _load():
             "H5Tget_sign": (ctypes.c_int, [_hid]),
             "H5Tis_variable_str": (ctypes.c_int, [_hid]),
             "H5Lexists": (ctypes.c_int, [_hid, ctypes.c_char_p, _hid]),
+            "H5Dset_extent": (ctypes.c_int, [_hid, ctypes.POINTER(_hsz)]),
+            "H5Sselect_hyperslab": (ctypes.c_int, [_hid, ctypes.c_int, ctypes.POINTER(_hsz), ctypes.POINTER(_hsz),
+                                                   ctypes.POINTER(_hsz), ctypes.POINTER(_hsz)]),
             "H5Eset_auto2": (ctypes.c_int, [_hid, ctypes.c_void_p, ctypes.c_void_p]),
         }
         for name, (res, args) in sig.items():
@@ -179,6 +182,46 @@ class Dataset(object):
 
     def __len__(self):
         return self.shape[0]
+
+    def resize(self, shape):
+        """New extent of a dataset created with maxshape (h5py's Dataset.resize)."""
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        assert len(shape) == len(self.shape)
+        if _load().H5Dset_extent(self._id, (_hsz * len(shape))(*shape)) < 0:
+            raise IOError("h5lite: cannot resize dataset %s to %s (created without maxshape?)" % (self.name, shape))
+        self.shape = shape
+
+    def __setitem__(self, key, value):
+        """dset[n:] = rows / dset[n:, :] = rows: the rows from n on (what StatServer.write(mode='a') needs)."""
+        lib = _load()
+        k0 = key[0] if isinstance(key, tuple) else key
+        rest = key[1:] if isinstance(key, tuple) else ()
+        if not (isinstance(k0, slice) and k0.step in (None, 1) and all(r == slice(None) for r in rest)):
+            raise NotImplementedError("h5lite: only dset[n:m] = rows")
+        n0, n1, _ = k0.indices(self.shape[0])
+        a = np.asarray(value)
+        if a.dtype.kind == "U":
+            a = a.astype("S")
+        if a.dtype.kind != "S":
+            a = a.astype(self.dtype)
+        a = np.ascontiguousarray(a)
+        assert a.shape == (n1 - n0,) + self.shape[1:], (a.shape, (n1 - n0,) + self.shape[1:])
+        if a.size == 0:
+            return
+        nd = len(self.shape)
+        fs = lib.H5Dget_space(self._id)
+        start = (_hsz * nd)(n0, *([0] * (nd - 1)))
+        count = (_hsz * nd)(*a.shape)
+        lib.H5Sselect_hyperslab(fs, 0, start, None, count, None)
+        ms = lib.H5Screate_simple(nd, count, None)
+        mt, owned = _file_type(a.dtype)
+        rc = lib.H5Dwrite(self._id, mt, ms, fs, H5P_DEFAULT, a.ctypes.data_as(ctypes.c_void_p))
+        if owned:
+            lib.H5Tclose(mt)
+        lib.H5Sclose(ms)
+        lib.H5Sclose(fs)
+        if rc < 0:
+            raise IOError("h5lite: cannot write rows %d..%d of dataset %s" % (n0, n1, self.name))
 
     def _close(self):
         if self._id:

@@ -108,13 +108,32 @@ class StatServer(object):
                 prefix + "stat0": self.stat0.astype(np.float32),
                 prefix + "stat1": self.stat1.astype(np.float32),
                 prefix + "start": start, prefix + "stop": stop}
+        # mode 'a' on a file that exists: every dataset grows and the new rows go behind the old ones, no check for
+        # duplicated entries (statserver.py:408-476)
+        grow = mode != "w" and os.path.exists(output_file_name)
         if output_file_name.endswith((".h5", ".hdf5")):
             h5py = _h5()
             with h5py.File(output_file_name, mode) as f:
-                for k, v in data.items():
-                    f.create_dataset(k, data=v, maxshape=(None,) + v.shape[1:], compression="gzip",
-                                     fletcher32=True)
+                if grow and (prefix + "modelset") in f:
+                    previous_size = f[prefix + "modelset"].shape[0]
+                    for k, v in data.items():
+                        f[k].resize((previous_size + v.shape[0],) + v.shape[1:])
+                    for k, v in data.items():
+                        f[k][previous_size:] = v
+                else:
+                    for k, v in data.items():
+                        f.create_dataset(k, data=v, maxshape=(None,) + v.shape[1:], compression="gzip",
+                                         fletcher32=True)
         else:
+            if grow:
+                z = np.load(output_file_name, allow_pickle=False)
+                old = {k: z[k] for k in z.files}
+                for k, v in data.items():
+                    if k in old:
+                        w = max(old[k].dtype.itemsize, v.dtype.itemsize) if v.dtype.kind == "S" else None
+                        data[k] = np.concatenate([old.pop(k).astype("S%d" % w), v.astype("S%d" % w)]) if w else \
+                            np.concatenate([old.pop(k), v])
+                data.update(old)
             with open(output_file_name, "wb") as f:
                 np.savez(f, **data)
 

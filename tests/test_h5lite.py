@@ -104,6 +104,24 @@ def test_mixture_statserver_factor_analyser_h5_products(tmp_path):
     np.testing.assert_array_equal(sub.stat1, rd.stat1[[7, 1, 4]])
     with h5lite.File(fs, "r") as f:
         assert f["stat0"].dtype == np.float32 and f["stat1"].dtype == np.float32 and f["modelset"].dtype.kind == "S"
+    # mode 'a' on an existing file: the datasets grow, the new rows follow the old ones (statserver.py:450-476)
+    more = sk.StatServer()
+    more.modelset = np.array(["m9", "m-with-a-longer-name"])
+    more.segset = np.array(["seg-90", "seg-91"])
+    more.start = np.empty(2, "|O")
+    more.stop = np.empty(2, "|O")
+    more.stat0 = rs.uniform(0, 30, size=(2, C))
+    more.stat1 = rs.randn(2, C * D)
+    for ext in (".h5", ".npz"):
+        fg = str(tmp_path / ("grow" + ext))
+        ss.write(fg)
+        more.write(fg, mode="a")
+        both = sk.StatServer.read(fg)
+        assert both.stat0.shape == (S + 2, C) and list(both.segset[-2:]) == ["seg-90", "seg-91"]
+        assert both.modelset[S] == "m9" and both.modelset[S + 1].startswith("m-")      # fixed-length ids of the first write (HDF5)
+        np.testing.assert_array_equal(both.stat1[:S], rd.stat1)
+        np.testing.assert_array_equal(both.stat1[S:], more.stat1.astype(np.float32).astype(np.float64))
+        assert both.start[2] == 10 and both.start[S] is None
     ss.write(fs, prefix="second/")                         # a second StatServer under a prefix (statserver.py:418-449)
     with h5lite.File(fs, "r") as f:
         assert "second/stat1" in f and "stat1" not in f    # mode 'w' starts a new file, as h5py does
