@@ -2364,21 +2364,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
             if ((c & 1) == 0) ls[frame] = m[0];
             wave_lds_fence();
             float sm[16];
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const f32x4 m4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float acc1 = 0.f;
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) {
-                        const float ev = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + j] - m4[j]);
-                        lg[ct][4 * q4 + j] = ev;
-                        acc1 += ev;
-                    }
-                    sm[4 * q4 + j] = acc1;
-                }
-            }
+            tile_exp_sum<NCT>(lg, ls + 4 * h, sm);
             lane_reduce16(sm, c, OpAdd());
             // publish this wave's row of partials (the flag follows below, once the stores have drained)
             if ((c & 1) == 0) {
