@@ -152,6 +152,7 @@ int skm_moments(void *ctx, const float *X_dev, long T, int D, double *out_dev,
 #define SKM_GEMM_F64_F32OUT 3  /* double MFMA, C float                                                  */
 #define SKM_GEMM_F32_F64OUT 4  /* float MFMA, plain float accumulation (short K), C double               */
 #define SKM_GEMM_F32S_F32   5  /* float MFMA on 16x16x4 tiles (64 x 64 workgroup tiles: batches of small matrices), C float */
+#define SKM_GEMM_F32S_F64OUT 6 /* the same 64 x 64-tile float kernel, plain float accumulation, C double (ragged rank-sized products) */
 
 /* Strided-batched row-major GEMM  C[z] = alpha op(A[z]) op(B[z]) + beta C[z]  (all pointers dev; trans
  * flags mean "stored transposed").  Replaces the numpy.dot call sites of the TV path that are plain

@@ -82,5 +82,6 @@ static inline GemmArgs skm_gemm_args(const void *A, const void *B, void *C, int 
 //   SKM_GEMM_F64_F64     A,B double, C double
 //   SKM_GEMM_F64_F32OUT  A,B double, C float
 //   SKM_GEMM_F32S_F32    A,B float,  C float, 64 x 64 tiles of 16 x 16 x 4 MFMAs (batches of small matrices)
+//   SKM_GEMM_F32S_F64OUT the same kernel, C double (rank-sized products whose rank is far from a multiple of 128)
 int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStream_t st, const char *tag);
 

@@ -317,7 +317,8 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
     SKM_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0 && batch > 0, "gemm(%s): bad shape M=%d N=%d K=%d batch=%d", tag,
                 g.M, g.N, g.K, batch);
     const int tile = (kind == SKM_GEMM_F32_F32 || kind == SKM_GEMM_F32_F64ACC || kind == SKM_GEMM_F32_F64OUT) ? 128 : 64;
-    SKM_REQUIRE(kind != SKM_GEMM_F32S_F32 || !g.colmap, "gemm(%s): the small-tile float32 kernel has no column map", tag);
+    SKM_REQUIRE((kind != SKM_GEMM_F32S_F32 && kind != SKM_GEMM_F32S_F64OUT) || !g.colmap,
+                "gemm(%s): the small-tile float32 kernel has no column map", tag);
     const int ncols = g.tri_n > 0 ? g.tri_n : g.N;
     dim3 grid((ncols + tile - 1) / tile, (g.M + tile - 1) / tile, batch);
     SKM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm(%s): grid too large", tag);
@@ -361,12 +362,12 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
         else if (!g.transA && g.transB) hipLaunchKernelGGL((k_gemm<TI_, TO_, ACC_, G_, true, true>), grid, dim3(512), 0, st, gv);   \
         else hipLaunchKernelGGL((k_gemm<TI_, TO_, ACC_, G_, false, true>), grid, dim3(512), 0, st, gv);              \
     } while (0)
-#define SKM_GEMM_LS(G_)                                                                                             \
+#define SKM_GEMM_LS(TO_, G_)                                                                                        \
     do {                                                                                                             \
-        if (!g.transA && !g.transB) hipLaunchKernelGGL((k_gemm<float, float, false, G_, true, false, true>), grid, dim3(512), 0, st, gv);      \
-        else if (g.transA && !g.transB) hipLaunchKernelGGL((k_gemm<float, float, false, G_, false, false, true>), grid, dim3(512), 0, st, gv); \
-        else if (!g.transA && g.transB) hipLaunchKernelGGL((k_gemm<float, float, false, G_, true, true, true>), grid, dim3(512), 0, st, gv);   \
-        else hipLaunchKernelGGL((k_gemm<float, float, false, G_, false, true, true>), grid, dim3(512), 0, st, gv);   \
+        if (!g.transA && !g.transB) hipLaunchKernelGGL((k_gemm<float, TO_, false, G_, true, false, true>), grid, dim3(512), 0, st, gv);      \
+        else if (g.transA && !g.transB) hipLaunchKernelGGL((k_gemm<float, TO_, false, G_, false, false, true>), grid, dim3(512), 0, st, gv); \
+        else if (!g.transA && g.transB) hipLaunchKernelGGL((k_gemm<float, TO_, false, G_, true, true, true>), grid, dim3(512), 0, st, gv);   \
+        else hipLaunchKernelGGL((k_gemm<float, TO_, false, G_, false, true, true>), grid, dim3(512), 0, st, gv);     \
     } while (0)
 #define SKM_GEMM_GO(TI_, TO_, ACC_)                    \
     do {                                               \
@@ -380,8 +381,12 @@ int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStre
     case SKM_GEMM_F64_F64: SKM_GEMM_GO(double, double, false); break;
     case SKM_GEMM_F64_F32OUT: SKM_GEMM_GO(double, float, false); break;
     case SKM_GEMM_F32S_F32:
-        if (guard) SKM_GEMM_LS(true);
-        else SKM_GEMM_LS(false);
+        if (guard) SKM_GEMM_LS(float, true);
+        else SKM_GEMM_LS(float, false);
+        break;
+    case SKM_GEMM_F32S_F64OUT:
+        if (guard) SKM_GEMM_LS(double, true);
+        else SKM_GEMM_LS(double, false);
         break;
     default: skm_set_error("gemm(%s): unknown kind %d", tag, kind); return SKM_ERR_ARG;
     }

@@ -66,6 +66,10 @@ __global__ __launch_bounds__(256) void k_tv_whiten(const TS *__restrict__ stat0,
 // only, the panel products read rows above their block, e_hh / A are consumed as upper triangles.
 #define TV_CS_SPLIT 16   // session ranges of the e_hh column sums
 #define TV_AUX_CHUNK 2048 // k per float32 accumulation run of the aux product (float64 across runs)
+// The aux product has N = R columns; R = 400 is 3 x 128 + 16 and the 128-wide kernel spends a whole (guarded) tile
+// column on the 16: 1.07 ms per 50 000 x 400 x 2048 chunk against 0.73 ms for the 64 x 64-tile kernel (7 columns of 64,
+// tools/time_aux_shapes.py).  The C accumulation (M = R) is the other way round (3.7 against 3.9 ms) and stays.
+#define TV_AUX_KIND SKM_GEMM_F32S_F64OUT
 static inline long tv_tri_cols(int R)
 {
     long n = 0;
@@ -442,11 +446,11 @@ struct TvWs {
 
 // split-K factor of the aux = f~ T GEMM.  Every K chunk is a launch of its own (float32 sums over TV_AUX_CHUNK terms,
 // float64 across chunks), and a launch whose 128 x 128 output tiles make only a few rounds over the 2 x CU resident
-// workgroups idles in its last round: 50 000 sessions x R = 400 are 1564 tiles = 3.05 rounds, a quarter of the fourth
-// lost sixty times.  Splitting K over slabs puts several chunks into one launch until it has at least 8 rounds.
+// workgroups idles in its last round: with 128 x 128 tiles 50 000 sessions x R = 400 were 1564 tiles = 3.05 rounds, a
+// quarter of the fourth lost sixty times.  Splitting K over slabs puts several chunks into one launch until it has at least 8 rounds.
 static int tv_ksplit(int cu, long S, int R, int C)
 {
-    const long tiles = ((S + 127) / 128) * ((R + 127) / 128);
+    const long tiles = ((S + 63) / 64) * ((R + 63) / 64);      // 64 x 64 tiles (TV_AUX_KIND)
     int ks = 1;
     while (ks < 16 && tiles * ks < 16L * cu && C % (ks * 2) == 0) ks *= 2;
     return ks;
@@ -636,7 +640,7 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
             g.sC = S * R;
             g.beta = k0 ? 1.0 : 0.0;
             g.swz = 2;          // the R/128 column tiles share the f~ row tile
-            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, g, w.ksplit, st, "k_gemm_aux"))) return rc;
+            if ((rc = skm_gemm_launch(ctx, TV_AUX_KIND, g, w.ksplit, st, "k_gemm_aux"))) return rc;
         }
         SkmProfScope ps(ctx, "k_sum_slabs", st);
         hipLaunchKernelGGL(k_sum_slabs, dim3(ctx->cu_count * 2), dim3(256), 0, st, aux, slabs, S * R, w.ksplit);
@@ -647,7 +651,7 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
             GemmArgs g = skm_gemm_args(ftilde + k0, T32 + k0 * R, aux, (int)S, R, kn, CD, R, R);
             g.beta = k0 ? 1.0 : 0.0;
             g.swz = 2;
-            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, g, 1, st, "k_gemm_aux"))) return rc;
+            if ((rc = skm_gemm_launch(ctx, TV_AUX_KIND, g, 1, st, "k_gemm_aux"))) return rc;
         }
     }
     const bool chain64 = tv_chain_f64();

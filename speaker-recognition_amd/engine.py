@@ -442,7 +442,7 @@ class HipEngine(object):
         return out, lab_out, out_off
 
     # ------------------------------------------------------------------ total variability
-    GEMM_F32_F32, GEMM_F32_F64ACC, GEMM_F64_F64, GEMM_F64_F32OUT, GEMM_F32_F64OUT, GEMM_F32S_F32 = 0, 1, 2, 3, 4, 5
+    GEMM_F32_F32, GEMM_F32_F64ACC, GEMM_F64_F64, GEMM_F64_F32OUT, GEMM_F32_F64OUT, GEMM_F32S_F32, GEMM_F32S_F64OUT = 0, 1, 2, 3, 4, 5, 6
 
     def gemm(self, A, B, C=None, transA=False, transB=False, alpha=1.0, beta=0.0, kind=None):
         """C = alpha op(A) op(B) + beta C on 2-D contiguous device tensors (float32 or float64)."""
