@@ -211,7 +211,8 @@ def main():
     ap.add_argument("--em2048-frames", type=int, default=12_500_000, help="frames per GPU of the em_c2048 leg")
     ap.add_argument("--bw-sessions", type=int, default=50_000, help="sessions of the bw_stats leg, all ranks together")
     ap.add_argument("--tv-sessions", type=int, default=50_000, help="sessions of the tv leg, all ranks together")
-    ap.add_argument("--tv-batch", type=int, default=4096, help="sessions per TV E-step batch")
+    ap.add_argument("--tv-batch", type=int, default=4096, help="sessions per TV E-step batch (training)")
+    ap.add_argument("--tv-extract-batch", type=int, default=16384, help="sessions per batch of extract_ivectors")
     ap.add_argument("--api-sessions", type=int, default=4000, help="sessions of the host-in / host-out samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs")
@@ -626,9 +627,9 @@ def main():
         dt_tv, _ = timed(tv_iter, 1)
         prof_tv = eng.profile_read()
         T32, G = eng.tv_prepare(tv_state["T"], Ct, D)
-        dt_iv, _ = timed(lambda: eng.tv_estep(naug, ft, T32, G, Ct, D, batch=args.tv_batch, uncertainty=False), 1)
+        dt_iv, _ = timed(lambda: eng.tv_estep(naug, ft, T32, G, Ct, D, batch=args.tv_extract_batch, uncertainty=False), 1)
         prof_iv = eng.profile_read()
-        dt_ivu, _ = timed(lambda: eng.tv_estep(naug, ft, T32, G, Ct, D, batch=args.tv_batch, uncertainty=True), 1)
+        dt_ivu, _ = timed(lambda: eng.tv_estep(naug, ft, T32, G, Ct, D, batch=args.tv_extract_batch, uncertainty=True), 1)
         eng.profile_read()
         eng.profile(False)
         flop_train, flop_iv = 9.18e8, 4.5e8          # algorithmic flop per session
