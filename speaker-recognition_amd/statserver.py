@@ -219,8 +219,12 @@ class StatServer(object):
         kept = []                         # (rows, stat0 f32, stat1 f32) device blocks when keep_on_device
 
         def store(rows, s0, s1):
-            self.stat0[rows, :] = eng.to_host(s0)
-            self.stat1[rows, :] = eng.to_host(s1)
+            if hasattr(eng, "to_host_rows"):        # pinned, pipelined copy off the device (engine.to_host_rows)
+                eng.to_host_rows(s0, self.stat0, rows)
+                eng.to_host_rows(s1, self.stat1, rows)
+            else:
+                self.stat0[rows, :] = eng.to_host(s0)
+                self.stat1[rows, :] = eng.to_host(s1)
             if keep_on_device:
                 kept.append((list(rows), s0.to(torch.float32), s1.to(torch.float32)))
 
