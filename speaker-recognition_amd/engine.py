@@ -717,6 +717,40 @@ class HipEngine(object):
     def to_host(self, t):
         return t.detach().cpu().numpy()
 
+    def upload_rows(self, a, dtype=None, chunk_bytes=64 << 20):
+        """Device copy of a 2-D host array, converted to `dtype` ON THE DEVICE (same IEEE rounding as numpy's astype),
+        through two page-locked staging buffers: the host copy of one chunk into its buffer overlaps the transfer of the
+        previous one.  (`torch.from_numpy(a.astype(float32)).to(device)` converts on one host core and then moves
+        pageable memory.)"""
+        torch = self.torch
+        a = np.asarray(a)
+        assert a.ndim == 2
+        src_dtype = torch.from_numpy(np.empty(0, dtype=a.dtype)).dtype
+        dtype = dtype or src_dtype
+        n, w = a.shape
+        out = torch.empty((n, w), dtype=dtype, device=self.device)
+        if n == 0 or w == 0:
+            return out
+        per = max(1, int(chunk_bytes // (w * a.dtype.itemsize)))
+        key = ("up", src_dtype, per * w)
+        if getattr(self, "_pin_up_key", None) != key:
+            self._pin_up = [torch.empty(per * w, dtype=src_dtype, pin_memory=True) for _ in range(2)]
+            self._pin_up_ev = [torch.cuda.Event() for _ in range(2)]
+            self._pin_up_used = [False, False]
+            self._pin_up_key = key
+        st = torch.cuda.current_stream(self.device)
+        for k, r0 in enumerate(range(0, n, per)):
+            r1 = min(n, r0 + per)
+            j = k & 1
+            if self._pin_up_used[j]:
+                self._pin_up_ev[j].synchronize()          # the transfer that last read this buffer is done
+            buf = self._pin_up[j][:(r1 - r0) * w].view(r1 - r0, w)
+            buf.numpy()[...] = a[r0:r1]
+            out[r0:r1].copy_(buf.to(self.device, non_blocking=True) if dtype != src_dtype else buf, non_blocking=True)
+            self._pin_up_ev[j].record(st)
+            self._pin_up_used[j] = True
+        return out
+
     def to_host_rows(self, t, out, rows=None, chunk_bytes=64 << 20):
         """out[rows] = t (a 2-D device tensor; rows None: out[:] = t) through two page-locked staging buffers: the copy
         of one chunk off the device overlaps the host copy of the previous one into `out`.  A plain `.cpu()` into

@@ -24,8 +24,9 @@ def _load_stat_arrays(src, prefix=''):
     """(modelset, segset, start, stop, stat0, stat1) with stat0/stat1 as STORED (float32 for files,
     which is what the reference's TV code consumes, statserver.py:439-446)."""
     if isinstance(src, StatServer):
-        return (src.modelset, src.segset, src.start, src.stop,
-                np.asarray(src.stat0).astype(np.float32), np.asarray(src.stat1).astype(np.float32))
+        # float64 in memory; the rounding to float32 that a file would apply happens where the rows are uploaded
+        # (engine.upload_rows(..., float32): on the device, and only for the rank's rows)
+        return (src.modelset, src.segset, src.start, src.stop, np.asarray(src.stat0), np.asarray(src.stat1))
     a = StatServer._load_arrays(src, prefix)
     start = np.empty(a["start"].shape, '|O')
     stop = np.empty(a["stop"].shape, '|O')
@@ -33,6 +34,13 @@ def _load_stat_arrays(src, prefix=''):
     stop[a["stop"] != -1] = a["stop"][a["stop"] != -1]
     return (a["modelset"], a["segset"], start, stop,
             np.asarray(a["stat0"], dtype=np.float32), np.asarray(a["stat1"], dtype=np.float32))
+
+
+def _upload_f32(eng, a):
+    """Rows of stored statistics on the device as float32 (the storage type of a StatServer file)."""
+    if hasattr(eng, "upload_rows"):
+        return eng.upload_rows(a, eng.torch.float32)
+    return eng.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(eng.device)
 
 
 # Sessions per device batch of extract_ivectors: no e_hh / A accumulation there, so the batch is bounded by scratch only
@@ -144,8 +152,8 @@ class FactorAnalyser(object):
             local.append((total + a, total + b))
             total += n
             if b > a:
-                d0 = torch.from_numpy(np.ascontiguousarray(s0[a:b])).to(eng.device)
-                d1 = torch.from_numpy(np.ascontiguousarray(s1[a:b])).to(eng.device)
+                d0 = _upload_f32(eng, s0[a:b])
+                d1 = _upload_f32(eng, s1[a:b])
                 ft, naug = eng.tv_whiten(d0, d1, ubm.get_mean_super_vector(), ubm.get_invcov_super_vector())
                 fts.append(ft)
                 naugs.append(naug)
