@@ -141,3 +141,84 @@ def test_mixture_statserver_factor_analyser_h5_products(tmp_path):
     assert fb.G is None and fb.H is None
     with h5lite.File(ff, "r") as f:                        # fa/* layout and the kind vector of factor_analyser.py:264-290
         assert f.keys() == ["fa"] and list(f["fa/kind"][()]) == [1, 1, 0, 0, 1]
+
+
+def _idmap():
+    m = sk.IdMap()
+    m.set(np.array(["spk1", "spk1", "spk22"], dtype="|O"), np.array(["a/b", "c", "dd"], dtype="|O"),
+          start=[None, 10, 0], stop=[None, 250, 99])
+    return m
+
+
+@pytest.mark.parametrize("ext", [".h5", ".npz"])
+def test_idmap_ndx_scores_files(tmp_path, ext):
+    """The bosaris containers keep the reference's HDF5 datasets (idmap.py:84-115, ndx.py:93-112,
+    scores.py:94-115) and read back what they wrote."""
+    m = _idmap()
+    p = str(tmp_path / ("idmap" + ext))
+    m.write(p)
+    r = sk.IdMap.read(p)
+    assert list(r.leftids) == list(m.leftids) and list(r.rightids) == list(m.rightids)
+    assert list(r.start) == [None, 10, 0] and list(r.stop) == [None, 250, 99]
+    r2 = sk.IdMap(p)
+    assert list(r2.rightids) == list(m.rightids)
+
+    ndx = sk.Ndx(models=np.array(["m1", "m2", "m1"]), testsegs=np.array(["s1", "s1", "s3"]))
+    p = str(tmp_path / ("ndx" + ext))
+    ndx.write(p)
+    for back in (sk.Ndx.read(p), sk.Ndx(p)):
+        assert list(back.modelset) == ["m1", "m2"] and list(back.segset) == ["s1", "s3"]
+        assert np.array_equal(back.trialmask, [[True, True], [True, False]])
+
+    sc = sk.Scores()
+    sc.modelset, sc.segset = ndx.modelset, ndx.segset
+    sc.scoremask = ndx.trialmask.copy()
+    sc.scoremat = np.array([[1.5, -2.25], [0.125, 0.0]])
+    p = str(tmp_path / ("scores" + ext))
+    sc.write(p)
+    back = sk.Scores.read(p)
+    assert np.array_equal(back.scoremat, sc.scoremat) and np.array_equal(back.scoremask, sc.scoremask)
+    assert list(back.modelset) == ["m1", "m2"]
+    if ext == ".h5":
+        with sk.h5lite.File(str(tmp_path / "idmap.h5"), "r") as f:
+            assert f["start"][()].dtype == np.int32 and f["leftids"][()].dtype.kind == "S"
+        with sk.h5lite.File(str(tmp_path / "ndx.h5"), "r") as f:
+            assert f["trial_mask"][()].dtype == np.int8
+        pm = str(tmp_path / "scores_matlab.h5")
+        sc.write_matlab(pm)
+        back = sk.Scores.read_matlab(pm)
+        assert np.array_equal(back.scoremat, sc.scoremat) and list(back.segset) == ["s1", "s3"]
+
+
+def test_bosaris_text_files(tmp_path):
+    m = _idmap()
+    p = str(tmp_path / "idmap.txt")
+    m.write_txt(p)
+    r = sk.IdMap.read_txt(p)
+    assert list(r.leftids) == list(m.leftids) and list(r.start) == [None, 10, 0] and list(r.stop) == [None, 250, 99]
+    with open(str(tmp_path / "two.txt"), "w") as fh:
+        fh.write("spk1 a\nspk2 b\n")
+    r = sk.IdMap.read_txt(str(tmp_path / "two.txt"))
+    assert list(r.rightids) == ["a", "b"] and list(r.start) == [None, None]
+
+    ndx = sk.Ndx(models=np.array(["m2", "m1", "m1"]), testsegs=np.array(["s1", "s1", "s3"]))
+    p = str(tmp_path / "ndx.txt")
+    ndx.save_txt(p)
+    back = sk.Ndx.read_txt(p)
+    assert list(back.modelset) == ["m1", "m2"] and np.array_equal(back.trialmask, ndx.trialmask)
+
+    sc = sk.Scores()
+    sc.modelset, sc.segset, sc.scoremask = ndx.modelset, ndx.segset, ndx.trialmask.copy()
+    sc.scoremat = np.array([[1.5, -2.25], [0.125, 7.0]])
+    p = str(tmp_path / "scores.txt")
+    sc.write_txt(p)
+    back = sk.Scores.read_txt(p)
+    assert np.array_equal(back.scoremask, sc.scoremask)
+    assert np.array_equal(back.scoremat, np.where(sc.scoremask, sc.scoremat, 0.0))
+
+    class Key:
+        modelset, segset = np.array(["m2", "m1"]), np.array(["s3", "s1"])
+        tar = np.array([[False, True], [True, False]])
+        non = np.array([[True, False], [False, True]])
+    tar, non = back.get_tar_non(Key)
+    assert sorted(tar) == [-2.25, 0.125] and list(non) == [1.5]     # (m2, s3) was never scored
