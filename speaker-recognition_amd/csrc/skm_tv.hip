@@ -448,6 +448,16 @@ struct TvWs {
 // float64 across chunks), and a launch whose 128 x 128 output tiles make only a few rounds over the 2 x CU resident
 // workgroups idles in its last round: with 128 x 128 tiles 50 000 sessions x R = 400 were 1564 tiles = 3.05 rounds, a
 // quarter of the fourth lost sixty times.  Splitting K over slabs puts several chunks into one launch until it has at least 8 rounds.
+// R = 400 is 3.125 row tiles of 128 but 6.25 of 64: the 64-wide tile is the default (48.0 -> 43.7 ms per 50 000 sessions), SKM_TV_CACC=big restores the 128-wide one
+static int tv_cacc_kind()
+{
+    static const int kind = [] {
+        const char *e = getenv("SKM_TV_CACC");
+        return (e && !strcmp(e, "big")) ? SKM_GEMM_F32_F64OUT : SKM_GEMM_F32S_F64OUT;
+    }();
+    return kind;
+}
+
 static int tv_ksplit(int cu, long S, int R, int C)
 {
     const long tiles = ((S + 63) / 64) * ((R + 63) / 64);      // 64 x 64 tiles (TV_AUX_KIND)
@@ -704,7 +714,7 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
             c.transA = 1;
             c.beta = 1.0;
             c.swz = 1;      // the R/128 row tiles share the f~ column tile
-            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, c, 1, st, "k_gemm_cacc"))) return rc;
+            if ((rc = skm_gemm_launch(ctx, tv_cacc_kind(), c, 1, st, "k_gemm_cacc"))) return rc;
         }
     }
     return SKM_OK;
