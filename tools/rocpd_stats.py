@@ -8,6 +8,8 @@ import sys
 
 
 def main():
+    if len(sys.argv) != 3 or not sys.argv[2].endswith('.csv'):
+        sys.exit(__doc__)      # a shell glob that matched two databases would make the second one the output
     db, out = sys.argv[1], sys.argv[2]
     con = sqlite3.connect(db)
     rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
