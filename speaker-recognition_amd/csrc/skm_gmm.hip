@@ -1217,6 +1217,9 @@ __device__ __forceinline__ void wset_load(WSet<NCT> &w, const WStream &ws, int N
 
 __device__ __forceinline__ f32x4 wfrag_load(const WStream &ws, int soff)
 {
+#ifdef SKM_ABL_W0
+    soff = 0;
+#endif
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, ws.sbase + soff, 0));
 }
 
@@ -1546,17 +1549,22 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
             // reloaded from scratch in front of every tile's first MFMA
             float k = kcv[ct];
             asm volatile("" : "+v"(k));
+#ifdef SKM_ABL_NOSPLAT
+            asm volatile("" : "=v"(lg[ct]));
+#else
 #pragma unroll
             for (int r = 0; r < 16; ++r) lg[ct][r] = k;
+#endif
         }
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
 #ifdef SKM_TRACE
         gemm_logits_fat<NCT, GEO>(lg, wa, xt + c * g.XS, h, Wg4, g, trace_now ? a.trace + wave * 16 : nullptr);
-#else
+#elif !defined(SKM_ABL_NOLOGITS)
         gemm_logits_fat<NCT, GEO>(lg, wa, xt + c * g.XS, h, Wg4, g);
 #endif
         SKM_STAMP(1);
+#ifndef SKM_ABL_NOLSE
 
         // exact per-frame maximum over this wave's NCT*32 components, e = 2^(l - max), per-frame sum of e
         float m[16];
@@ -1572,12 +1580,14 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
             partm[(pslot * NWV + wave) * 32 + frame] = m[0];
             parts[(pslot * NWV + wave) * 32 + frame] = sm[0];
         }
+#endif
         SKM_STAMP(2);
         // next tile goes to the buffer last read two tiles ago (every wave is past that tile's barrier)
         if (has_next) store_pre(xs + nxt * tile_floats);
         SKM_STAMP(3);
         __syncthreads();
         SKM_STAMP(4);
+#ifndef SKM_ABL_NOLSE
         {
             const float *pmv = partm + pslot * NWV * 32 + c;
             const float *psv = parts + pslot * NWV * 32 + c;
@@ -1602,6 +1612,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
                 lg[ct][4 * q4 + 3] *= f4[3];
             }
         }
+#endif
         // frames of tile+2 are requested here: the statistics GEMM that follows has no other vector-memory
         // wait, so the HBM latency never sits in front of an in-order vmcnt wait of the W stream
         if (tile + 2 < tb) {
@@ -1611,7 +1622,9 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
         SKM_STAMP(5);
+#ifndef SKM_ABL_NOSTATS
         gemm_stats_agpr<NJT, NCT>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
+#endif
         SKM_STAMP(6);
         wave_lds_fence();
         cur = nxt;

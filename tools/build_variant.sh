@@ -1,0 +1,12 @@
+#!/bin/bash
+# A variant of libskm.so for timing studies: skm_gmm.hip recompiled with extra -D flags, the other objects reused.
+#   tools/build_variant.sh <name> -DSKM_ABL_NOLSE ...   ->  tools/ab/libskm_<name>.so   (select with SKM_LIB=...)
+set -euo pipefail
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+CS="$ROOT/speaker-recognition_amd/csrc"
+name="$1"; shift
+mkdir -p "$ROOT/tools/ab"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" "$@" -c "$CS/skm_gmm.hip" -o "$ROOT/tools/ab/skm_gmm_$name.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$ROOT/tools/ab/skm_gmm_$name.o" "$CS/obj/skm_backend.o" "$CS/obj/skm_feat.o" "$CS/obj/skm_gemm.o" "$CS/obj/skm_tv.o" -o "$ROOT/tools/ab/libskm_$name.so"
+rm -f "$ROOT/tools/ab/skm_gmm_$name.o"
+echo "built tools/ab/libskm_$name.so"
