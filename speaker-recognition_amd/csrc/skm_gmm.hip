@@ -1412,6 +1412,9 @@ template <int NCT, int NJT, int GEO, int PRE>
 __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
 {
     constexpr int NF = 2 * NJT, NFW = NF * 32;   // PRE = floats staged per thread: 8 (4 waves) or 16 (2 waves)
+    // the wide-row instantiations (one component tile per wave) are only launched with 16-byte rows: without the
+    // scalar staging path their tile loop keeps its 20 / 40 staging registers out of scratch
+    constexpr bool VEC4 = (NCT == 1);
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, NWV = nthr >> 6;
@@ -1461,7 +1464,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
     for (int i = 0; i < NST; ++i) {
         // vec4: element = float4 index; scalar geometry: elements are handled 4 consecutive floats per slot
         const int e = tid + i * nthr;
-        if (g.vec4) {
+        if (VEC4 || g.vec4) {
             const int n4 = g.D >> 2;
             const int row = e / n4;
             st_src[i] = e;
@@ -1474,7 +1477,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
         }
     }
     auto load_pre = [&](long t0, int nvalid) __attribute__((always_inline)) {
-        if (g.vec4) {
+        if (VEC4 || g.vec4) {
             const f32x4 *X4 = reinterpret_cast<const f32x4 *>(a.X + t0 * (long)g.D);
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
@@ -1496,7 +1499,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
         }
     };
     auto store_pre = [&](float *dst) __attribute__((always_inline)) {
-        if (g.vec4) {
+        if (VEC4 || g.vec4) {
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
                 if (st_row[i] < 32) {
@@ -2798,6 +2801,9 @@ struct Plan {
     int n_llk;
     // single-sweep kernel (7..16 component tiles, D <= 63)
     int fused, fused_nwv, fused_blocks, fused_fat, fat_blocks;
+    // wide rows (65 <= D+1 <= 160, C <= 128): the fat kernel with ONE component tile per wave, 2 or 4 waves
+    int wide, wide_nwv, wide_blocks;
+    size_t wide_lds;
     size_t fused_lds;
     // one-wave single-sweep kernel (1..4 component tiles): component tiles per wave, workgroups (= waves)
     int solo, solo_nct, solo_blocks;
@@ -2897,6 +2903,18 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
     }
     p->fused_lds = ((size_t)3 * 32 * g.XS + (size_t)4 * p->fused_nwv * 32 + (size_t)p->fused_nwv * 32 +
                     (size_t)p->fused_nwv * 2 * 16 * 64) * sizeof(float);
+    // wide rows: 3..5 statistics column tiles leave room for ONE component tile per 512-register wave (2 * NJT
+    // accumulator tiles = 96..160 AGPRs), so a workgroup of 2 or 4 waves holds up to 128 components; staging
+    // needs 32*D <= 20 floats * 256 threads (40 * 128)
+    {
+        const char *e = getenv("SKM_WIDE");
+        p->wide = (with_s && g.NJT >= 3 && g.NJT <= 5 && g.CT <= 4 && D % 4 == 0 && 32 * D <= 5120 &&
+                   (e ? atoi(e) != 0 : 1)) ? 1 : 0;
+        p->wide_nwv = g.CT <= 2 ? 2 : 4;
+        p->wide_blocks = wgs * (p->wide_nwv == 2 ? 2 : 1);
+        if (p->wide_blocks > p->n_llk) p->wide_blocks = p->n_llk;
+        p->wide_lds = ((size_t)3 * 32 * g.XS + (size_t)4 * p->wide_nwv * 32 + (size_t)p->wide_nwv * 32) * sizeof(float);
+    }
     // team kernel: EM statistics, C a multiple of 512 above 512, 16-byte rows with D <= 64, and a CU count
     // that splits into teams of B workgroups per XCD (blocks are dealt round-robin over 8 XCDs)
     {
@@ -2935,6 +2953,8 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         if (p->solo && slsolo > sl) sl = slsolo;
         const size_t slteam = (size_t)p->team_wgs * 4 * 128 * nf * 32 * sizeof(double);
         if (p->team && slteam > sl) sl = slteam;
+        const size_t slwide = (size_t)p->wide_blocks * p->wide_nwv * 32 * nf * 32 * sizeof(double);
+        if (p->wide && slwide > sl) sl = slwide;
         off += skm_align_up(sl, 256);
     }
     p->off_flags = off;     // flags and err are cleared by one memset: keep them adjacent
@@ -3122,6 +3142,55 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
         SkmProfScope ps(ctx, "k_reduce_slabs", st);
         hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + SKM_RED_OUT - 1) / SKM_RED_OUT)), dim3(256), 0, st, f.slabs, 1, nblk,
                            1, p.solo_nct, p.g.NJT, nf, C, D, out, accumulate, f.llk_part, p.n_llk);
+        SKM_HIP(hipGetLastError());
+        return SKM_OK;
+    }
+    if (p.wide) {
+        // single sweep for wide rows (D = 64..159, C <= 128): the fat kernel with one component tile per wave
+        FusedArgs f;
+        memset(&f, 0, sizeof(f));
+        f.X = X;
+        f.T = T;
+        f.g = p.tg;
+        f.wp = wp;
+        f.kc = kc;
+        f.slabs = reinterpret_cast<double *>(ws + p.off_slabs);
+        f.llk_part = reinterpret_cast<double *>(ws + p.off_llk);
+        f.stagger = 1;
+        f.flush_tiles = skm_flush_tiles();
+        const int nwv = p.wide_nwv, nblk = p.wide_blocks, nf = 2 * p.g.NJT;
+        SKM_HIP(hipMemsetAsync(f.llk_part, 0, p.n_llk * sizeof(double), st));
+        {
+            SkmProfScope ps(ctx, "k_estep_fat", st);
+            const int geo = ((p.tg.NP & 1) ? 2 : 0) | (p.tg.tail ? 1 : 0);
+#define SKM_WIDE_LAUNCH(NJT_, GEO_)                                                                             \
+    do {                                                                                                       \
+        if (nwv == 4) {                                                                                        \
+            if ((rc = set_lds(k_estep_fat<1, NJT_, GEO_, 20>, p.wide_lds))) return rc;                         \
+            hipLaunchKernelGGL((k_estep_fat<1, NJT_, GEO_, 20>), dim3(nblk), dim3(256), p.wide_lds, st, f);    \
+        } else {                                                                                               \
+            if ((rc = set_lds(k_estep_fat<1, NJT_, GEO_, 40>, p.wide_lds))) return rc;                         \
+            hipLaunchKernelGGL((k_estep_fat<1, NJT_, GEO_, 40>), dim3(nblk), dim3(128), p.wide_lds, st, f);    \
+        }                                                                                                      \
+    } while (0)
+#define SKM_WIDE_GEO(NJT_)                                                                                      \
+    do {                                                                                                       \
+        if (geo == 0) SKM_WIDE_LAUNCH(NJT_, 0);                                                                \
+        else if (geo == 1) SKM_WIDE_LAUNCH(NJT_, 1);                                                           \
+        else if (geo == 2) SKM_WIDE_LAUNCH(NJT_, 2);                                                           \
+        else SKM_WIDE_LAUNCH(NJT_, 3);                                                                         \
+    } while (0)
+            if (p.g.NJT == 3) SKM_WIDE_GEO(3);
+            else if (p.g.NJT == 4) SKM_WIDE_GEO(4);
+            else SKM_WIDE_GEO(5);
+#undef SKM_WIDE_GEO
+#undef SKM_WIDE_LAUNCH
+        }
+        SKM_HIP(hipGetLastError());
+        const long n_out = (long)C * nf * 32;
+        SkmProfScope ps(ctx, "k_reduce_slabs", st);
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + SKM_RED_OUT - 1) / SKM_RED_OUT)), dim3(256), 0, st, f.slabs, nwv, nblk,
+                           1, 1, p.g.NJT, nf, C, D, out, accumulate, f.llk_part, p.n_llk);
         SKM_HIP(hipGetLastError());
         return SKM_OK;
     }
@@ -3321,7 +3390,7 @@ extern "C" int skm_gmm_estep_noalloc(void *ctx_, const float *X, long T, int C, 
     Plan p;
     int rc = make_plan(ctx, 0, C, D, true, &p);          // layout without the T-sized two-sweep regions
     if (rc) return rc;
-    const bool single = p.solo || p.fused || (p.team && p.team_B >= 2);
+    const bool single = p.solo || p.wide || p.fused || (p.team && p.team_B >= 2);
     if (!single && (rc = make_plan(ctx, T, C, D, true, &p))) return rc;
     if (p.total > SKM_SCRATCH_BYTES) {
         skm_set_error("skm_gmm_estep_noalloc: T=%ld C=%d D=%d needs %zu bytes of scratch, the built-in array holds %zu "

@@ -79,6 +79,12 @@ def test_estep_vs_reference_golden(eng, tag):
                                    # without a tail group) at one, two and four component tiles; several tiles per wave
                                    (64, 20, 320), (64, 4, 320), (128, 36, 5000), (20, 36, 320), (100, 28, 777), (17, 16, 100),
                                    (128, 60, 300000), (32, 60, 200000), (48, 13, 150000),
+                                   # wide rows (D = 64 .. 156, C <= 128): one component tile per wave, 2 or 4 waves; every
+                                   # ending of the logits GEMM at 3, 4 and 5 statistics column tiles; padding tiles (C = 17,
+                                   # 32, 40, 96, 100); several folds per wave
+                                   (64, 64, 3000), (128, 68, 5000), (32, 72, 777), (96, 76, 4097), (64, 96, 320),
+                                   (128, 100, 300000), (17, 104, 100), (100, 108, 2049), (128, 128, 3000),
+                                   (64, 132, 200000), (40, 136, 1234), (128, 140, 999), (64, 156, 5000),
                                    # team kernel (C = 1024 / 2048 / 4096): ragged last tile, fewer tiles than teams, one frame
                                    (1024, 60, 9999), (2048, 20, 12345), (2048, 60, 95), (1024, 64, 1), (4096, 60, 4100)])
 def test_estep_vs_oracle_shapes(eng, C, D, T):

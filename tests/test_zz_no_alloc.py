@@ -27,6 +27,7 @@ def _rel(a, b):
                                        (128, 60, 20000, 999),        # one-wave kernel, four component tiles
                                        (64, 13, 3000, 777),          # one-wave kernel, two tiles, scalar staging
                                        (20, 24, 5000, 31),           # one-wave kernel, one tile
+                                       (64, 132, 9000, 500),         # wide rows: one component tile per wave, two waves
                                        (160, 13, 3000, 777)])        # two sweeps: per-frame partials in the scratch
 def test_noalloc_equals_workspace_entry_point(eng, C, D, T1, T2):
     torch = eng.torch
