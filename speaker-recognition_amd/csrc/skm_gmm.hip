@@ -1812,11 +1812,11 @@ __global__ __launch_bounds__(64, NCT == 1 ? 2 : 1) void k_estep_solo(FusedArgs a
 // workgroups co-resident or the launch fails and the host falls back to two sweeps); every poll loop is
 // bounded and raises *err instead of spinning forever.
 // ------------------------------------------------------------------------------------------------
-// Baum-Welch flush of AGPR accumulators (one store per session, see flush_session); C is a multiple of
-// NCT * 32 for every caller, so every accumulator row is a live component.
+// Baum-Welch flush of AGPR accumulators (one store per session, see flush_session).  Rows at or beyond C are
+// padding components (kc = -1e30, gamma = 0) of a model that does not fill its last component block.
 template <int NCT, int NF>
 __device__ __forceinline__ void flush_session_agpr(f32x16 (&acc)[NCT][NF], double *s0, double *s1, int cb, int D,
-                                                   int lane, bool add = false)
+                                                   int lane, bool add, int C)
 {
     const int h = lane >> 5, c = lane & 31;
 #pragma unroll
@@ -1829,7 +1829,7 @@ __device__ __forceinline__ void flush_session_agpr(f32x16 (&acc)[NCT][NF], doubl
             const int comp0 = (cb * NCT + ct) * 32 + 4 * h;
             double *p = (col < D) ? (s1 + (long)comp0 * D + col) : (s0 + comp0);
             const long stride = (col < D) ? D : 1;
-            if (col <= D) {
+            if (col <= D && comp0 + 27 < C) {      // every row of this lane is a live component
                 if (!add) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) p[acc_row(r, 0) * stride] = (double)v[r];
@@ -1840,6 +1840,13 @@ __device__ __forceinline__ void flush_session_agpr(f32x16 (&acc)[NCT][NF], doubl
 #pragma unroll
                     for (int r = 0; r < 16; ++r) p[acc_row(r, 0) * stride] = old[r] + (double)v[r];
                 }
+            } else if (col <= D && comp0 < C) {    // the model ends inside this component tile
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (comp0 + acc_row(r, 0) < C) {
+                        double *q = p + acc_row(r, 0) * stride;
+                        *q = (add ? *q : 0.0) + (double)v[r];
+                    }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
@@ -1918,7 +1925,7 @@ struct TeamArgs {
 template <int NCT, int NJT, int B, int GEO>
 __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
 {
-    constexpr int NF = 2 * NJT, NFW = NF * 32, PRE = 8, RING = 4;
+    constexpr int NF = 2 * NJT, NFW = NF * 32, PRE = (NJT >= 3) ? 20 : 8, RING = 4;   // PRE: see k_seg_team
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), NWV = 4;
@@ -2187,7 +2194,8 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
 template <int NCT, int NJT, int B, bool BW, int GEO>
 __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
 {
-    constexpr int NF = BW ? NJT : 2 * NJT, NFW = NF * 32, PRE = 8, RING = 4, NC = 4 * B;
+    // PRE floats of a frame tile staged per thread: 32 * D <= PRE * 256 (rows of up to 160 floats at NJT >= 3)
+    constexpr int NF = BW ? NJT : 2 * NJT, NFW = NF * 32, PRE = (NJT >= 3) ? 20 : 8, RING = 4, NC = 4 * B;
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), NWV = 4;
@@ -2483,7 +2491,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
                 const long pe = (pb + 32L * SKM_FLUSH_TILES < se0) ? pb + 32L * SKM_FLUSH_TILES : se0;
                 run_segment(pb, pe);
                 flush_session_agpr<NCT, NF>(acc, a.stat0 + (long)sidx * a.C, a.stat1 + (long)sidx * a.C * g.D, me, g.D,
-                                            lane, pb > sb0);
+                                            lane, pb > sb0, a.C);
                 pb = pe;
             } while (pb < se0);
         }
@@ -2809,7 +2817,7 @@ struct Plan {
     int solo, solo_nct, solo_blocks;
     size_t solo_lds;
     // team kernel (C > 512 in multiples of 512): B workgroups per team, teams of one XCD share blockIdx % 8
-    int team, team_B, team_per_xcd, team_wgs;
+    int team, team_B, team_per_xcd, team_wgs, team_nct;
     size_t team_lds, off_xch, off_flags, off_err;
     // workspace offsets (bytes)
     size_t off_pm, off_ps, off_lse, off_llk, off_slabs, total;
@@ -2925,7 +2933,41 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         p->team_wgs = 8 * p->team_per_xcd * B;
         p->team = (g.CT == g.CTpad && g.CTpad % 16 == 0 && (B == 1 || B == 2 || B == 4 || B == 8) && p->team_per_xcd >= 1 &&
                    D % 4 == 0 && D <= 64 && g.NJT <= 2 && (e ? atoi(e) != 0 : 1)) ? 1 : 0;
-        p->team_lds = ((size_t)4 * 32 * g.XS + 4 * 32 + (size_t)4 * 4 * 4 * 64 * 4) * sizeof(float);
+        p->team_nct = 4;
+        // EM on wide rows above 128 components: ONE component tile per wave (2 * NJT accumulator tiles), teams of
+        // C/128 workgroups; the last workgroup's waves may sit on padding tiles (k_reduce_slabs reads comp < C only)
+        if (with_s && !p->team && !p->wide && g.NJT >= 3 && g.NJT <= 5 && D % 4 == 0 && 32 * D <= 5120) {
+            const int Bw = g.CTpad / 4;
+            const int per_xcd = Bw > 0 ? (wgs / 8) / Bw : 0;
+            if ((Bw == 2 || Bw == 4 || Bw == 8 || Bw == 16) && per_xcd >= 1 && (e ? atoi(e) != 0 : 1) &&
+                !getenv("SKM_NO_WIDE_TEAM")) {
+                p->team = 1;
+                p->team_nct = 1;
+                p->team_B = Bw;
+                p->team_per_xcd = per_xcd;
+                p->team_wgs = 8 * per_xcd * Bw;
+            }
+        }
+        // Baum-Welch (no S accumulators: NCT * NJT tiles) also runs the segment kernel on smaller component blocks:
+        // ONE component tile per wave (C <= 128, a team of one workgroup) or two (blocks of 256 components, teams
+        // of 1, 2, 4 or 8), and on wide rows (3..5 column tiles, 32 * D <= 20 floats * 256 threads).  The last
+        // block may be padding (kc = -1e30): flush_session_agpr skips rows at or beyond C.
+        if (!with_s && !p->team) {
+            const char *es = getenv("SKM_BW_SMALL");
+            const bool rows_ok = D % 4 == 0 && (g.NJT <= 2 || (g.NJT <= 5 && 32 * D <= 5120));
+            const int nct = g.CT <= 4 ? 1 : (g.CTpad % 8 == 0 ? 2 : 0);
+            const int Bs = nct ? g.CTpad / (4 * nct) : 0;
+            const int per_xcd = Bs > 0 ? (wgs / 8) / Bs : 0;
+            if (rows_ok && nct && (Bs == 1 || ((Bs == 2 || Bs == 4 || Bs == 8) && g.NJT >= 3)) && per_xcd >= 1 &&
+                (e ? atoi(e) != 0 : 1) && (es ? atoi(es) != 0 : 1)) {
+                p->team = 1;
+                p->team_nct = nct;
+                p->team_B = Bs;
+                p->team_per_xcd = per_xcd;
+                p->team_wgs = 8 * per_xcd * Bs;
+            }
+        }
+        p->team_lds = ((size_t)4 * 32 * g.XS + 4 * 32 + (size_t)4 * p->team_nct * 4 * 64 * 4) * sizeof(float);
     }
     size_t off = 0;
     p->off_pm = off;
@@ -2951,7 +2993,7 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         if (p->fused && slf > sl) sl = slf;
         const size_t slsolo = (size_t)p->solo_blocks * p->solo_nct * 32 * nf * 32 * sizeof(double);
         if (p->solo && slsolo > sl) sl = slsolo;
-        const size_t slteam = (size_t)p->team_wgs * 4 * 128 * nf * 32 * sizeof(double);
+        const size_t slteam = (size_t)p->team_wgs * 4 * p->team_nct * 32 * nf * 32 * sizeof(double);
         if (p->team && slteam > sl) sl = slteam;
         const size_t slwide = (size_t)p->wide_blocks * p->wide_nwv * 32 * nf * 32 * sizeof(double);
         if (p->wide && slwide > sl) sl = slwide;
@@ -2970,9 +3012,10 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
 extern "C" size_t skm_gmm_workspace_bytes(void *ctx, long T, int C, int D)
 {
     if (!ctx) return 0;
-    Plan p;
+    Plan p, q;      // one workspace serves the EM entry points and skm_bw_stats (its plan may use a team where EM's does not)
     if (make_plan(static_cast<SkmCtx *>(ctx), T, C, D, true, &p) != SKM_OK) return 0;
-    return p.total;
+    if (make_plan(static_cast<SkmCtx *>(ctx), T, C, D, false, &q) != SKM_OK) return 0;
+    return p.total > q.total ? p.total : q.total;
 }
 
 template <typename K>
@@ -3283,7 +3326,7 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
         t.trace = g_trace;
 #endif
         const int nf = 2 * p.g.NJT;
-        SKM_HIP(hipMemsetAsync(t.slabs, 0, (size_t)p.team_wgs * 4 * 128 * nf * 32 * sizeof(double), st));
+        SKM_HIP(hipMemsetAsync(t.slabs, 0, (size_t)p.team_wgs * 4 * p.team_nct * 32 * nf * 32 * sizeof(double), st));
         SKM_HIP(hipMemsetAsync(t.llk_part, 0, p.n_llk * sizeof(double), st));
         SKM_HIP(hipMemsetAsync(t.flags, 0, p.off_xch - p.off_flags, st));
         void *kargs[] = {&t};
@@ -3305,6 +3348,24 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
     } while (0)
             le = hipErrorInvalidValue;
             const int geo = ((p.tg.NP & 1) ? 2 : 0) | (p.tg.tail ? 1 : 0);
+#define SKM_TEAMW_LAUNCH(NJT_, B_)                                                                                 \
+    do {                                                                                                          \
+        if ((rc = set_lds(k_estep_team<1, NJT_, B_, -1>, p.team_lds))) return rc;                                 \
+        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_estep_team<1, NJT_, B_, -1>),            \
+                                        dim3(p.team_wgs), dim3(256), kargs, (unsigned)p.team_lds, st);            \
+    } while (0)
+#define SKM_TEAMW_B(NJT_)                                                                                          \
+    do {                                                                                                          \
+        if (p.team_B == 2) SKM_TEAMW_LAUNCH(NJT_, 2);                                                             \
+        else if (p.team_B == 4) SKM_TEAMW_LAUNCH(NJT_, 4);                                                        \
+        else if (p.team_B == 8) SKM_TEAMW_LAUNCH(NJT_, 8);                                                        \
+        else SKM_TEAMW_LAUNCH(NJT_, 16);                                                                          \
+    } while (0)
+            if (p.team_nct == 1) {  // wide rows: one component tile per wave, run-time geometry
+                if (p.g.NJT == 3) SKM_TEAMW_B(3);
+                else if (p.g.NJT == 4) SKM_TEAMW_B(4);
+                else SKM_TEAMW_B(5);
+            } else
             if (p.g.NJT == 1) {     // D < 32: geometry stays a run-time branch (fewer instantiations)
                 if (p.team_B == 2) SKM_TEAM_LAUNCH(1, 2, -1);
                 else if (p.team_B == 4) SKM_TEAM_LAUNCH(1, 4, -1);
@@ -3316,12 +3377,14 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
             }
 #undef SKM_TEAM_GEO
 #undef SKM_TEAM_LAUNCH
+#undef SKM_TEAMW_B
+#undef SKM_TEAMW_LAUNCH
         }
         if (le == hipSuccess) {
             const long n_out = (long)C * nf * 32;
             SkmProfScope ps(ctx, "k_reduce_slabs", st);
             hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + SKM_RED_OUT - 1) / SKM_RED_OUT)), dim3(256), 0, st, t.slabs,
-                               4 * p.team_B, 8 * p.team_per_xcd, 1, 4, p.g.NJT, nf, C, D, out, accumulate, t.llk_part,
+                               4 * p.team_B, 8 * p.team_per_xcd, 1, p.team_nct, p.g.NJT, nf, C, D, out, accumulate, t.llk_part,
                                p.n_llk, t.err);
             SKM_HIP(hipGetLastError());
             return SKM_OK;
@@ -3494,6 +3557,31 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
         else SKM_TEAM_LAUNCH(2, B_, 3);                                                                           \
     } while (0)
             const int geo = ((p.tg.NP & 1) ? 2 : 0) | (p.tg.tail ? 1 : 0);
+#define SKM_BWS_LAUNCH(NCT_, NJT_, B_)                                                                             \
+    do {                                                                                                          \
+        if ((rc = set_lds(k_seg_team<NCT_, NJT_, B_, true, -1>, p.team_lds))) return rc;                          \
+        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_seg_team<NCT_, NJT_, B_, true, -1>),     \
+                                        dim3(p.team_wgs), dim3(256), kargs, (unsigned)p.team_lds, st);            \
+    } while (0)
+#define SKM_BWS_WIDE(NJT_)                                                                                         \
+    do {                                                                                                          \
+        if (p.team_nct == 1) SKM_BWS_LAUNCH(1, NJT_, 1);                                                          \
+        else if (p.team_B == 1) SKM_BWS_LAUNCH(2, NJT_, 1);                                                       \
+        else if (p.team_B == 2) SKM_BWS_LAUNCH(2, NJT_, 2);                                                       \
+        else if (p.team_B == 4) SKM_BWS_LAUNCH(2, NJT_, 4);                                                       \
+        else SKM_BWS_LAUNCH(2, NJT_, 8);                                                                          \
+    } while (0)
+            if (p.team_nct != 4) {      // smaller component blocks / wide rows (run-time geometry of the logits ending)
+                if (p.g.NJT == 1) {
+                    if (p.team_nct == 1) SKM_BWS_LAUNCH(1, 1, 1);
+                    else SKM_BWS_LAUNCH(2, 1, 1);
+                } else if (p.g.NJT == 2) {
+                    if (p.team_nct == 1) SKM_BWS_LAUNCH(1, 2, 1);
+                    else SKM_BWS_LAUNCH(2, 2, 1);
+                } else if (p.g.NJT == 3) SKM_BWS_WIDE(3);
+                else if (p.g.NJT == 4) SKM_BWS_WIDE(4);
+                else SKM_BWS_WIDE(5);
+            } else
             if (p.g.NJT == 1) {
                 if (p.team_B == 1) SKM_TEAM_LAUNCH(1, 1, -1);
                 else if (p.team_B == 2) SKM_TEAM_LAUNCH(1, 2, -1);
@@ -3507,6 +3595,8 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
             }
 #undef SKM_TEAM_GEO
 #undef SKM_TEAM_LAUNCH
+#undef SKM_BWS_WIDE
+#undef SKM_BWS_LAUNCH
         }
         if (le == hipSuccess) {
             // a timed-out hand-off must not return numbers: consume the flag on the stream

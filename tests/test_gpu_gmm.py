@@ -85,6 +85,10 @@ def test_estep_vs_reference_golden(eng, tag):
                                    (64, 64, 3000), (128, 68, 5000), (32, 72, 777), (96, 76, 4097), (64, 96, 320),
                                    (128, 100, 300000), (17, 104, 100), (100, 108, 2049), (128, 128, 3000),
                                    (64, 132, 200000), (40, 136, 1234), (128, 140, 999), (64, 156, 5000),
+                                   # wide rows above 128 components: teams of C/128 workgroups (2, 4, 8, 16), padding tiles in the
+                                   # last workgroup (C = 448), fewer tiles than teams, several folds
+                                   (256, 132, 3000), (512, 100, 70000), (1024, 68, 4097), (2048, 132, 2500), (448, 128, 999),
+                                   (256, 64, 600000),
                                    # team kernel (C = 1024 / 2048 / 4096): ragged last tile, fewer tiles than teams, one frame
                                    (1024, 60, 9999), (2048, 20, 12345), (2048, 60, 95), (1024, 64, 1), (4096, 60, 4100)])
 def test_estep_vs_oracle_shapes(eng, C, D, T):
@@ -192,6 +196,49 @@ def test_bw_stats_team_kernel_ragged_and_empty_sessions(eng, C, D):
     finally:
         del os.environ["SKM_TEAM"]
     assert rel(s0, eng.to_host(t0)) < 5e-5 and rel(s1, eng.to_host(t1)) < 5e-5   # two float32 paths, each within 1e-4 of the oracle
+
+
+@pytest.mark.parametrize("C,D", [(64, 132), (128, 60), (32, 20), (100, 64), (40, 156), (128, 128), (17, 100),    # one tile per wave
+                                 (256, 60), (200, 36), (130, 8), (256, 100), (512, 132), (480, 72), (1024, 96),  # two tiles per wave
+                                 (2048, 68)])
+def test_bw_stats_small_blocks_and_wide_rows(eng, C, D):
+    """Baum-Welch on the single-sweep segment kernel below 512 components (one or two component tiles per wave, a team
+    of one workgroup) and on rows of 64..159 features (teams of 256-component workgroups): ragged / empty sessions,
+    models that end inside a component tile or leave whole waves on padding; against the oracle and against the
+    two-sweep path (SKM_BW_SMALL=0)."""
+    import os
+    gmm = orc.random_gmm(C, D, seed=C + D)
+    lens = [0, 0, 1, 31, 32, 33, 0, 257, 64, 1, 0, 700, 95, 0, 0]
+    frames = orc.synth_frames(sum(lens), dim=D, seed=10)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    X = eng.upload_frames(frames)
+    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    s0, s1 = eng.bw_stats(X, off, packed)
+    s0, s1 = eng.to_host(s0), eng.to_host(s1)
+    r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
+    assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
+    for i, n in enumerate(lens):
+        if n == 0:
+            assert np.all(s0[i] == 0) and np.all(s1[i] == 0)
+        else:
+            assert rel(s0[i], r0[i]) < TOL and rel(s1[i], r1[i]) < TOL
+    assert np.allclose(s0.sum(1), lens, rtol=1e-4)
+    os.environ["SKM_BW_SMALL"] = "0"
+    try:
+        t0, t1 = eng.bw_stats(X, off, packed)
+    finally:
+        del os.environ["SKM_BW_SMALL"]
+    # two float32 paths, each within 1e-4 of the oracle (logits of 2 * 156 terms round further apart than those of 120)
+    tol2 = 5e-5 if D <= 64 else 1e-4
+    assert rel(s0, eng.to_host(t0)) < tol2 and rel(s1, eng.to_host(t1)) < tol2
+    if C % 512 == 0 or D > 64:      # the environment switch really selects another kernel for these shapes
+        prof = {}
+        eng.profile(True)
+        eng.bw_stats(X, off, packed)
+        eng.torch.cuda.synchronize()
+        prof = eng.profile_read()
+        eng.profile(False)
+        assert "k_bw_team" in prof, prof
 
 
 @pytest.mark.parametrize("C,D", [(512, 60), (2048, 20)])
