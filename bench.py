@@ -23,6 +23,7 @@ Also reported on the same JSON line (rank 0):
                 sample of the same workload, host cores stated (N=1 only)
   em_split      BASELINE configs[1] whole: Mixture.EM_split to 512 components, 37 EM iterations over 9 splits
   em_c2048      BASELINE configs[2] per-GPU shard: EM iteration at C=2048 on 12.5 M frames per GPU (weak scaling)
+  cfg1          BASELINE configs[0] shape (the reference's conf.yaml UBM): EM iteration + Baum-Welch at C=64, D=132
   bw_stats      BASELINE configs[3]: Baum-Welch N/F, C=2048, 50 000 sessions x 2 000 frames in total, sessions
                 split over the ranks (strong scaling); `api` = host arrays in -> host arrays out on a bounded sample
   tv            BASELINE configs[4]: TV training iteration + extract_ivectors, R=400, C=2048, 50 000 sessions in
@@ -216,8 +217,8 @@ def main():
     ap.add_argument("--api-sessions", type=int, default=4000, help="sessions of the host-in / host-out samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs")
-    ap.add_argument("--legs", default="em_split,em2048,bw,scoring,feat,tv",
-                    help="secondary legs (comma list of em_split, em2048, bw, scoring, feat, tv)")
+    ap.add_argument("--legs", default="em_split,em2048,bw,cfg1,scoring,feat,tv",
+                    help="secondary legs (comma list of em_split, em2048, bw, cfg1, scoring, feat, tv)")
     ap.add_argument("--launch-check", action="store_true",
                     help="only report the rank layout the launcher produced (gloo, no GPU); used by the CPU tests")
     args = ap.parse_args()
@@ -456,6 +457,38 @@ def main():
                                                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                                 "frac": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
         del ubm_e, Xe
+
+    if "cfg1" in legs:
+        # ---- the reference's own configuration (BASELINE configs[0]: conf.yaml UBM, 64 diagonal components on 132-dim
+        # rows = 44 coefficients + deltas + double deltas): one EM iteration and the Baum-Welch pass, both on the
+        # wide-row single-sweep kernels (one component tile per 512-register wave)
+        C1, D1, T1, L1 = 64, 132, 4_000_000, 2000
+        X1 = synth_frames_device(torch, T1, D1, seed=77 + rank, device=dev)
+        ubm_1 = random_ubm(sk, C1, D1, seed=13)
+        em_iterations(ubm_1, X1, 1)
+        eng.profile(True)
+        dt1, _ = timed(lambda: em_iterations(ubm_1, X1, 2), 1)
+        dt1 /= 2
+        prof = eng.profile_read()
+        eng.profile(False)
+        kt1 = {k: v[1] / v[0] for k, v in prof.items()}
+        packed1 = eng.pack(ubm_1.w, ubm_1.mu, ubm_1.invcov)
+        seg1 = torch.arange(0, T1 // L1 + 1, dtype=torch.int64, device=dev) * L1
+        eng.bw_stats(X1, seg1, packed1)
+        eng.profile(True)
+        dtb1, _ = timed(lambda: eng.bw_stats(X1, seg1, packed1), 1)
+        profb = eng.profile_read()
+        eng.profile(False)
+        result["cfg1"] = {"value": world * T1 / dt1, "unit": "frames/s", "n_gpus": world, "ms_per_iteration": 1e3 * dt1,
+                          "workload": "UBM EM iteration and Baum-Welch statistics, C=%d, D=%d, %d frames per GPU in sessions of "
+                                      "%d (BASELINE configs[0] shape, synthetic frames)" % (C1, D1, T1, L1),
+                          "kernels_ms": {k: round(v, 3) for k, v in kt1.items()},
+                          "em_frac_of_mfma_peak": 8.0 * D1 * C1 * T1 / dt1 / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                          "bw_frames_per_s": world * T1 / dtb1,
+                          "bw_kernels_ms": {k: round(v[1] / v[0], 3) for k, v in profb.items()},
+                          "bw_frac_of_mfma_peak": 6.0 * D1 * C1 * T1 / dtb1 / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        del X1, ubm_1, packed1, seg1
+        torch.cuda.empty_cache()
 
     if "scoring" in legs:
         # ---- GMM-UBM LLR scoring (next row after the statistics path, gmm_scoring.py:56-119): every enrolled model

@@ -95,7 +95,9 @@ int skm_gmm_estep(void *ctx, const float *X_dev, long T, int C, int D, const voi
  * team hand-off rows) is a file-scope device array of skm_gmm_estep_noalloc_max_bytes() = 144 MiB that every GPU
  * the library runs on holds until the process ends.  The call allocates nothing (no hipMalloc / hipFree; keep
  * skm_prof_enable off, its events are created per launch).
- *   - shapes with a single-sweep kernel (C in {256, 512, 1024, 2048, 4096}, D % 4 == 0, D <= 64): any T;
+ *   - shapes with a single-sweep kernel (C <= 128 with D <= 63; 129..512 components with D <= 64; C in {1024, 2048,
+ *     4096} with D % 4 == 0 and D <= 64; rows of 64..159 features with D % 4 == 0 and C <= 128 or C/128 in
+ *     {2, 4, 8, 16}): any T;
  *   - other shapes take two sweeps whose per-frame partials live in the scratch too: T is bounded, and a call
  *     that does not fit returns SKM_ERR_WORKSPACE with the sizes in skm_last_error();
  *   - all calls on one GPU share that GPU's array: what must start at zero is cleared on `stream` by every
@@ -128,6 +130,13 @@ int skm_gmm_logprob(void *ctx, const float *X_dev, long T, int C, int D, const v
 int skm_bw_stats(void *ctx, const float *X_dev, long T, const int64_t *seg_off_dev, int S, int C, int D,
                  const void *packed_dev, double *stat0_dev, double *stat1_dev,
                  void *ws_dev, size_t ws_bytes, void *stream);
+
+/* Number of teams skm_bw_stats deals whole sessions to for a (C, D) model on this device, 0 when the shape takes the
+ * two-sweep kernels (which split sessions freely).  A host that holds FEW LONG sessions (fewer than a few per team)
+ * cuts them into 32-frame-aligned pieces itself, calls skm_bw_stats on the pieces and adds the rows of a session's
+ * pieces (speaker-recognition_amd/engine.py: _bw_split_plan).  No counterpart in the reference: its loop over
+ * sessions (sidekit/statserver.py:647-667) is serial. */
+int skm_bw_team_count(void *ctx, int C, int D);
 
 /* Mean of v over each segment [seg_off[s], seg_off[s+1]) (seg_off: S+1 int64, dev), float64 sums:
  * out_dev[s] = mean(v[seg_off[s] : seg_off[s+1]]); an empty segment gives NaN (numpy's mean of nothing).

@@ -2829,6 +2829,12 @@ static size_t lds_bytes(int nct, int nw, const GmmGeom &g)
 }
 
 // frame tiles a wave accumulates in f32 registers between two folds into its f64 slab
+static int skm_env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 static int skm_flush_tiles()
 {
     const char *e = getenv("SKM_FLUSH");
@@ -2896,7 +2902,9 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         if (p->solo_blocks > p->n_llk) p->solo_blocks = p->n_llk;
         p->solo_lds = ((size_t)2 * 32 * g.XS + 64) * sizeof(float);
     }
-    p->fused = (with_s && g.CT >= 7 && g.CT <= 16 && g.NJT <= 2 && !getenv("SKM_NO_FUSED")) ? 1 : 0;
+    // 5 or 6 component tiles run as 8 (two waves of four, padding tiles with kc = -1e30): C = 160 5.6 -> 4.2 ms per 4 M
+    // frames against the two sweeps, C = 192 5.5 -> 4.1
+    p->fused = (with_s && g.CT >= skm_env_int("SKM_FUSED_MIN_CT", 5) && g.CT <= 16 && g.NJT <= 2 && !getenv("SKM_NO_FUSED")) ? 1 : 0;
     p->fused_nwv = (g.CT + 1) / 2;
     p->fused_blocks = wgs * (p->fused_nwv <= 4 ? 2 : 1);
     if (p->fused_blocks > p->n_llk) p->fused_blocks = p->n_llk;
@@ -3625,6 +3633,14 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
     a.stat0 = stat0;
     a.stat1 = stat1;
     return launch_stats<false, true>(ctx, p, a, st);
+}
+
+extern "C" int skm_bw_team_count(void *ctx_, int C, int D)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    Plan p;
+    if (!ctx || C <= 0 || D <= 0 || make_plan(ctx, 0, C, D, false, &p) != SKM_OK) return 0;
+    return p.team ? 8 * p.team_per_xcd : 0;
 }
 
 extern "C" size_t skm_moments_workspace_bytes(void *ctx_, int D)

@@ -38,6 +38,7 @@ SIGNATURES = {
     "skm_gmm_estep": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                                _c_void_p, _c_size_t, _c_void_p]),
     "skm_gmm_estep_noalloc_max_bytes": (_c_size_t, []),
+    "skm_bw_team_count": (_c_int, [_c_void_p, _c_int, _c_int]),
     "skm_gmm_estep_noalloc": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                                        _c_void_p]),
     "skm_gmm_loglik": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p,
@@ -290,14 +291,17 @@ class HipEngine(object):
                                              _c_void_p(ws), need, self._stream()))
         return (lp, llk) if with_loglik else lp
 
-    def _bw_split_plan(self, seg_host, C):
-        """Few long sessions leave teams of the Baum-Welch kernel idle (whole sessions are dealt to C/512-workgroup
-        teams: 200 x 20 000 frames ran at 86 TF against 108 TF for 2000 x 2000).  Returns (piece offsets, owner of
-        each piece) when cutting the sessions into 32-frame-aligned pieces pays, else None."""
+    def _bw_split_plan(self, seg_host, C, D=60):
+        """Few long sessions leave teams of the Baum-Welch kernel idle (whole sessions are dealt to the teams of
+        workgroups that hold one copy of the model: 200 x 20 000 frames ran at 86 TF against 108 TF for 2000 x 2000).
+        Returns (piece offsets, owner of each piece) when cutting the sessions into 32-frame-aligned pieces pays,
+        else None."""
         S = seg_host.size - 1
-        if C < 512 or C % 512 or S == 0:
+        if S == 0:
             return None
-        teams = max(1, self.cu_count() // (C // 512))
+        teams = int(self.lib.skm_bw_team_count(self.ctx, int(C), int(D)))
+        if teams <= 0:
+            return None
         total = int(seg_host[-1] - seg_host[0])
         if S >= 4 * teams or total < 2048 * S:
             return None
@@ -324,7 +328,7 @@ class HipEngine(object):
         T, D = X.shape
         assert D == gmm.D and X.dtype == torch.float32 and X.is_contiguous()
         if split_long and not isinstance(seg_off, torch.Tensor):
-            plan = self._bw_split_plan(np.asarray(seg_off, dtype=np.int64), gmm.C)
+            plan = self._bw_split_plan(np.asarray(seg_off, dtype=np.int64), gmm.C, gmm.D)
             if plan is not None:
                 # statistics of the pieces, then the rows of a session's pieces are added: a float64 MFMA product
                 # with the 0/1 ownership matrix (exact weights, fixed summation order)

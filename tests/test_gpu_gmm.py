@@ -75,6 +75,7 @@ def test_estep_vs_reference_golden(eng, tag):
 
 @pytest.mark.parametrize("C,D,T", [(1, 60, 1000), (2, 60, 33), (33, 60, 4097), (512, 60, 20000), (96, 20, 5000),
                                    (64, 132, 3000), (130, 7, 2049), (256, 39, 7001), (2048, 60, 6000),
+                                   (160, 60, 5000), (192, 20, 3000), (135, 36, 70000),      # 5 or 6 component tiles: fat kernel with padding
                                    # one-wave kernel (C <= 128): every ending of the logits GEMM (pair count even / odd, with /
                                    # without a tail group) at one, two and four component tiles; several tiles per wave
                                    (64, 20, 320), (64, 4, 320), (128, 36, 5000), (20, 36, 320), (100, 28, 777), (17, 16, 100),
@@ -241,7 +242,7 @@ def test_bw_stats_small_blocks_and_wide_rows(eng, C, D):
         assert "k_bw_team" in prof, prof
 
 
-@pytest.mark.parametrize("C,D", [(512, 60), (2048, 20)])
+@pytest.mark.parametrize("C,D", [(512, 60), (2048, 20), (128, 60), (512, 132), (64, 132)])
 def test_bw_stats_few_long_sessions_are_split(eng, C, D):
     """Few long sessions on the team kernel: the host cuts them into 32-frame-aligned pieces (engine._bw_split_plan) and
     adds the pieces' rows with a 0/1 float64 product.  Same statistics as the unsplit launch (the float32 MFMA accumulators
@@ -251,7 +252,7 @@ def test_bw_stats_few_long_sessions_are_split(eng, C, D):
     lens = [5000, 0, 3001, 2049]
     frames = orc.synth_frames(sum(lens), dim=D, seed=32)
     off = np.concatenate([[0], np.cumsum(lens)])
-    plan = eng._bw_split_plan(off.astype(np.int64), C)
+    plan = eng._bw_split_plan(off.astype(np.int64), C, D)
     assert plan is not None and len(plan[1]) > len(lens)
     pieces, owner = plan
     assert pieces[0] == 0 and pieces[-1] == off[-1] and np.all(np.diff(pieces) >= 0)
