@@ -2939,7 +2939,9 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         p->team_B = B;
         p->team_per_xcd = (B > 0) ? (wgs / 8) / B : 0;
         p->team_wgs = 8 * p->team_per_xcd * B;
-        p->team = (g.CT == g.CTpad && g.CTpad % 16 == 0 && (B == 1 || B == 2 || B == 4 || B == 8) && p->team_per_xcd >= 1 &&
+        // (the last workgroup's last wave may hold padding tiles: kc = -1e30, gamma = 0, rows at or beyond C are skipped
+        // by k_reduce_slabs and flush_session_agpr)
+        p->team = (g.CTpad % 16 == 0 && (B == 1 || B == 2 || B == 4 || B == 8) && p->team_per_xcd >= 1 &&
                    D % 4 == 0 && D <= 64 && g.NJT <= 2 && (e ? atoi(e) != 0 : 1)) ? 1 : 0;
         p->team_nct = 4;
         // EM on wide rows above 128 components: ONE component tile per wave (2 * NJT accumulator tiles), teams of
@@ -2963,7 +2965,11 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         if (!with_s && !p->team) {
             const char *es = getenv("SKM_BW_SMALL");
             const bool rows_ok = D % 4 == 0 && (g.NJT <= 2 || (g.NJT <= 5 && 32 * D <= 5120));
-            const int nct = g.CT <= 4 ? 1 : (g.CTpad % 8 == 0 ? 2 : 0);
+            // measured against the two sweeps (4 M frames, sessions of 2000): D = 60: C = 64 2.5 vs 1.5 ms (two of four
+            // waves idle), C = 96 2.5 vs 2.9, C = 160 3.9 vs 4.9, C = 224 3.9 vs 5.8; D = 132: C = 32 4.3 vs 3.6,
+            // C = 64 4.3 vs 6.0, C = 512 15.5 vs 45.1
+            const int min_ct1 = g.NJT <= 2 ? 3 : 2;
+            const int nct = g.CT <= 4 ? (g.CT >= min_ct1 ? 1 : 0) : (g.CTpad % 8 == 0 ? 2 : 0);
             const int Bs = nct ? g.CTpad / (4 * nct) : 0;
             const int per_xcd = Bs > 0 ? (wgs / 8) / Bs : 0;
             if (rows_ok && nct && (Bs == 1 || ((Bs == 2 || Bs == 4 || Bs == 8) && g.NJT >= 3)) && per_xcd >= 1 &&

@@ -91,7 +91,8 @@ def test_estep_vs_reference_golden(eng, tag):
                                    (256, 132, 3000), (512, 100, 70000), (1024, 68, 4097), (2048, 132, 2500), (448, 128, 999),
                                    (256, 64, 600000),
                                    # team kernel (C = 1024 / 2048 / 4096): ragged last tile, fewer tiles than teams, one frame
-                                   (1024, 60, 9999), (2048, 20, 12345), (2048, 60, 95), (1024, 64, 1), (4096, 60, 4100)])
+                                   (1024, 60, 9999), (2048, 20, 12345), (2048, 60, 95), (1024, 64, 1), (4096, 60, 4100),
+                                   (1000, 60, 7000), (2040, 20, 3000), (900, 36, 50000)])       # last wave on padding tiles
 def test_estep_vs_oracle_shapes(eng, C, D, T):
     gmm = orc.random_gmm(C, D, seed=C + D)
     cep = orc.synth_frames(T, dim=D, clusters=16, seed=T)
@@ -199,9 +200,10 @@ def test_bw_stats_team_kernel_ragged_and_empty_sessions(eng, C, D):
     assert rel(s0, eng.to_host(t0)) < 5e-5 and rel(s1, eng.to_host(t1)) < 5e-5   # two float32 paths, each within 1e-4 of the oracle
 
 
-@pytest.mark.parametrize("C,D", [(64, 132), (128, 60), (32, 20), (100, 64), (40, 156), (128, 128), (17, 100),    # one tile per wave
+@pytest.mark.parametrize("C,D", [(64, 132), (128, 60), (96, 20), (100, 64), (40, 156), (128, 128), (17, 100),    # one tile per wave
                                  (256, 60), (200, 36), (130, 8), (256, 100), (512, 132), (480, 72), (1024, 96),  # two tiles per wave
-                                 (2048, 68)])
+                                 (2048, 68),
+                                 (448, 60), (1000, 20), (2040, 36)])      # four tiles per wave, the last wave on padding tiles
 def test_bw_stats_small_blocks_and_wide_rows(eng, C, D):
     """Baum-Welch on the single-sweep segment kernel below 512 components (one or two component tiles per wave, a team
     of one workgroup) and on rows of 64..159 features (teams of 256-component workgroups): ragged / empty sessions,
@@ -232,14 +234,15 @@ def test_bw_stats_small_blocks_and_wide_rows(eng, C, D):
     # two float32 paths, each within 1e-4 of the oracle (logits of 2 * 156 terms round further apart than those of 120)
     tol2 = 5e-5 if D <= 64 else 1e-4
     assert rel(s0, eng.to_host(t0)) < tol2 and rel(s1, eng.to_host(t1)) < tol2
-    if C % 512 == 0 or D > 64:      # the environment switch really selects another kernel for these shapes
-        prof = {}
-        eng.profile(True)
-        eng.bw_stats(X, off, packed)
-        eng.torch.cuda.synchronize()
-        prof = eng.profile_read()
-        eng.profile(False)
-        assert "k_bw_team" in prof, prof
+    # the kernel that ran is the one the plan names (a model of one component tile stays on the two sweeps: three of
+    # the four waves of a workgroup would sit on padding)
+    eng.profile(True)
+    eng.bw_stats(X, off, packed)
+    eng.torch.cuda.synchronize()
+    prof = eng.profile_read()
+    eng.profile(False)
+    assert ("k_bw_team" in prof) == (eng.lib.skm_bw_team_count(eng.ctx, C, D) > 0), prof
+    assert ("k_bw_team" in prof) == (not (C == 17)), prof
 
 
 @pytest.mark.parametrize("C,D", [(512, 60), (2048, 20), (128, 60), (512, 132), (64, 132)])
