@@ -28,7 +28,9 @@ def _rel(a, b):
                                        (64, 13, 3000, 777),          # one-wave kernel, two tiles, scalar staging
                                        (20, 24, 5000, 31),           # one-wave kernel, one tile
                                        (64, 132, 9000, 500),         # wide rows: one component tile per wave, two waves
-                                       (160, 13, 3000, 777)])        # two sweeps: per-frame partials in the scratch
+                                       (160, 13, 3000, 777),         # five component tiles run as eight (padding)
+                                       (1000, 60, 9000, 500),        # team kernel, last wave on padding tiles
+                                       (600, 13, 3000, 777)])        # two sweeps: per-frame partials in the scratch
 def test_noalloc_equals_workspace_entry_point(eng, C, D, T1, T2):
     torch = eng.torch
     gmm = orc.random_gmm(C, D, seed=C + D)
@@ -60,7 +62,7 @@ def test_noalloc_rejects_what_does_not_fit(eng):
     import sidekit_amd
     lib = eng.lib
     assert lib.skm_gmm_estep_noalloc_max_bytes() == 144 << 20
-    C, D, T = 160, 13, 10_000_000                                    # five component tiles: no single-sweep kernel
+    C, D, T = 600, 13, 10_000_000                                    # 19 component tiles: no single-sweep kernel
     gmm = orc.random_gmm(C, D, seed=1)
     packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
     # X really holds T frames: a library that failed to refuse the call would run it, not fault the card
