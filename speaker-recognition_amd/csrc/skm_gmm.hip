@@ -1854,43 +1854,70 @@ __device__ __forceinline__ void flush_session_agpr(f32x16 (&acc)[NCT][NF], doubl
         }
 }
 
-template <int PRE>
+// Cooperative staging of the contiguous 32 * D span of a frame tile (PRE floats per thread, 32 * D <= PRE * threads).
+// Rows of a multiple of 4 floats move as 16-byte pieces (a piece never straddles two rows).  GENERAL adds the path
+// for any D: single floats, row / column of every element fixed at init (the instantiations with a run-time logits
+// geometry carry it; the others are only launched with 16-byte rows).
+template <int PRE, bool GENERAL = false>
 struct TileStager {
-    static constexpr int NST = PRE / 4;
+    static constexpr int NST = PRE / 4, NIX = GENERAL ? PRE : NST;
     float pre[PRE];
-    int src[NST], dst[NST], row[NST];
+    int dst[NIX], row[NIX];
+    bool vec4;
     __device__ __forceinline__ void init(const TileGeom &g, int tid, int nthr)
     {
-        const int n4 = g.D >> 2;
+        vec4 = !GENERAL || g.vec4;
+        if (vec4) {
+            const int n4 = g.D >> 2;
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int e = tid + i * nthr, r = e / n4;
-            src[i] = e;
-            row[i] = (e < 32 * n4) ? r : 1 << 20;
-            dst[i] = r * g.XS + 4 * (e - r * n4);
+            for (int i = 0; i < NST; ++i) {
+                const int e = tid + i * nthr, r = e / n4;
+                row[i] = (e < 32 * n4) ? r : 1 << 20;
+                dst[i] = r * g.XS + 4 * (e - r * n4);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NIX; ++i) {
+                const int e = tid + i * nthr, r = e / g.D;
+                row[i] = (e < 32 * g.D) ? r : 1 << 20;
+                dst[i] = r * g.XS + (e - r * g.D);
+            }
         }
     }
     __device__ __forceinline__ void load(const float *__restrict__ X, long t0, int nvalid, int D)
     {
-        const f32x4 *X4 = reinterpret_cast<const f32x4 *>(X + t0 * (long)D);
+        const int tid = threadIdx.x, nthr = blockDim.x;
+        if (vec4) {
+            const f32x4 *X4 = reinterpret_cast<const f32x4 *>(X + t0 * (long)D);
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row[i] < nvalid) v = X4[src[i]];
-            pre[4 * i + 0] = v[0];
-            pre[4 * i + 1] = v[1];
-            pre[4 * i + 2] = v[2];
-            pre[4 * i + 3] = v[3];
+            for (int i = 0; i < NST; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row[i] < nvalid) v = X4[tid + i * nthr];
+                pre[4 * i + 0] = v[0];
+                pre[4 * i + 1] = v[1];
+                pre[4 * i + 2] = v[2];
+                pre[4 * i + 3] = v[3];
+            }
+        } else {
+            const float *Xs = X + t0 * (long)D;
+#pragma unroll
+            for (int i = 0; i < NIX; ++i) pre[i] = (row[i] < nvalid) ? Xs[tid + i * nthr] : 0.f;
         }
     }
     __device__ __forceinline__ void store(float *xs_tile) const
     {
+        if (vec4) {
 #pragma unroll
-        for (int i = 0; i < NST; ++i)
-            if (row[i] < 32) {
-                const f32x4 v = {pre[4 * i], pre[4 * i + 1], pre[4 * i + 2], pre[4 * i + 3]};
-                *reinterpret_cast<f32x4 *>(xs_tile + dst[i]) = v;
-            }
+            for (int i = 0; i < NST; ++i)
+                if (row[i] < 32) {
+                    const f32x4 v = {pre[4 * i], pre[4 * i + 1], pre[4 * i + 2], pre[4 * i + 3]};
+                    *reinterpret_cast<f32x4 *>(xs_tile + dst[i]) = v;
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NIX; ++i)
+                if (row[i] < 32) xs_tile[dst[i]] = pre[i];
+        }
     }
 };
 
@@ -1975,7 +2002,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
     bool dead = false;
     SKM_TRACE_DECL;
 
-    TileStager<PRE> stg;
+    TileStager<PRE, (GEO < 0 && NJT <= 2)> stg;
     stg.init(g, tid, nthr);
     if (ta < tb) {
         const long t0 = ta << 5;
@@ -2242,7 +2269,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
     unsigned n = 0;   // tiles this team has started: slot = n & 3, flag value = n + 1 (same on every member)
     SKM_TRACE_DECL;
 
-    TileStager<PRE> stg;
+    TileStager<PRE, (GEO < 0 && NJT <= 2)> stg;
     stg.init(g, tid, nthr);
     WSet<NCT> wa;
     wset_load<NCT>(wa, Wg4, g.NG, g.NP, 0);
@@ -2942,7 +2969,7 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         // (the last workgroup's last wave may hold padding tiles: kc = -1e30, gamma = 0, rows at or beyond C are skipped
         // by k_reduce_slabs and flush_session_agpr)
         p->team = (g.CTpad % 16 == 0 && (B == 1 || B == 2 || B == 4 || B == 8) && p->team_per_xcd >= 1 &&
-                   D % 4 == 0 && D <= 64 && g.NJT <= 2 && (e ? atoi(e) != 0 : 1)) ? 1 : 0;
+                   D <= 64 && g.NJT <= 2 && (e ? atoi(e) != 0 : 1)) ? 1 : 0;     // D % 4 != 0: run-time-geometry kernels
         p->team_nct = 4;
         // EM on wide rows above 128 components: ONE component tile per wave (2 * NJT accumulator tiles), teams of
         // C/128 workgroups; the last workgroup's waves may sit on padding tiles (k_reduce_slabs reads comp < C only)
@@ -2964,7 +2991,7 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         // block may be padding (kc = -1e30): flush_session_agpr skips rows at or beyond C.
         if (!with_s && !p->team) {
             const char *es = getenv("SKM_BW_SMALL");
-            const bool rows_ok = D % 4 == 0 && (g.NJT <= 2 || (g.NJT <= 5 && 32 * D <= 5120));
+            const bool rows_ok = g.NJT <= 2 || (D % 4 == 0 && g.NJT <= 5 && 32 * D <= 5120);
             // measured against the two sweeps (4 M frames, sessions of 2000): D = 60: C = 64 2.5 vs 1.5 ms (two of four
             // waves idle), C = 96 2.5 vs 2.9, C = 160 3.9 vs 4.9, C = 224 3.9 vs 5.8; D = 132: C = 32 4.3 vs 3.6,
             // C = 64 4.3 vs 6.0, C = 512 15.5 vs 45.1
@@ -3384,6 +3411,10 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
                 if (p.team_B == 2) SKM_TEAM_LAUNCH(1, 2, -1);
                 else if (p.team_B == 4) SKM_TEAM_LAUNCH(1, 4, -1);
                 else if (p.team_B == 8) SKM_TEAM_LAUNCH(1, 8, -1);
+            } else if (!p.tg.vec4) {    // rows that are not a multiple of 16 bytes: the staging path for any D
+                if (p.team_B == 2) SKM_TEAM_LAUNCH(2, 2, -1);
+                else if (p.team_B == 4) SKM_TEAM_LAUNCH(2, 4, -1);
+                else if (p.team_B == 8) SKM_TEAM_LAUNCH(2, 8, -1);
             } else {
                 if (p.team_B == 2) SKM_TEAM_GEO(2);
                 else if (p.team_B == 4) SKM_TEAM_GEO(4);
@@ -3601,6 +3632,11 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
                 else if (p.team_B == 2) SKM_TEAM_LAUNCH(1, 2, -1);
                 else if (p.team_B == 4) SKM_TEAM_LAUNCH(1, 4, -1);
                 else if (p.team_B == 8) SKM_TEAM_LAUNCH(1, 8, -1);
+            } else if (!p.tg.vec4) {    // rows that are not a multiple of 16 bytes: the staging path for any D
+                if (p.team_B == 1) SKM_TEAM_LAUNCH(2, 1, -1);
+                else if (p.team_B == 2) SKM_TEAM_LAUNCH(2, 2, -1);
+                else if (p.team_B == 4) SKM_TEAM_LAUNCH(2, 4, -1);
+                else if (p.team_B == 8) SKM_TEAM_LAUNCH(2, 8, -1);
             } else {
                 if (p.team_B == 1) SKM_TEAM_GEO(1);
                 else if (p.team_B == 2) SKM_TEAM_GEO(2);

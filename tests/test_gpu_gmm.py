@@ -92,7 +92,9 @@ def test_estep_vs_reference_golden(eng, tag):
                                    (256, 64, 600000),
                                    # team kernel (C = 1024 / 2048 / 4096): ragged last tile, fewer tiles than teams, one frame
                                    (1024, 60, 9999), (2048, 20, 12345), (2048, 60, 95), (1024, 64, 1), (4096, 60, 4100),
-                                   (1000, 60, 7000), (2040, 20, 3000), (900, 36, 50000)])       # last wave on padding tiles
+                                   (1000, 60, 7000), (2040, 20, 3000), (900, 36, 50000),        # last wave on padding tiles
+                                   # rows that are not a multiple of 16 bytes on the team kernels (staging float by float)
+                                   (2048, 39, 6000), (1024, 57, 9999), (4096, 13, 4100), (1024, 63, 70000), (2000, 19, 333)])
 def test_estep_vs_oracle_shapes(eng, C, D, T):
     gmm = orc.random_gmm(C, D, seed=C + D)
     cep = orc.synth_frames(T, dim=D, clusters=16, seed=T)
@@ -203,7 +205,8 @@ def test_bw_stats_team_kernel_ragged_and_empty_sessions(eng, C, D):
 @pytest.mark.parametrize("C,D", [(64, 132), (128, 60), (96, 20), (100, 64), (40, 156), (128, 128), (17, 100),    # one tile per wave
                                  (256, 60), (200, 36), (130, 8), (256, 100), (512, 132), (480, 72), (1024, 96),  # two tiles per wave
                                  (2048, 68),
-                                 (448, 60), (1000, 20), (2040, 36)])      # four tiles per wave, the last wave on padding tiles
+                                 (448, 60), (1000, 20), (2040, 36),       # four tiles per wave, the last wave on padding tiles
+                                 (2048, 39), (512, 57), (1024, 13), (128, 39), (256, 13), (96, 63)])   # rows of any length
 def test_bw_stats_small_blocks_and_wide_rows(eng, C, D):
     """Baum-Welch on the single-sweep segment kernel below 512 components (one or two component tiles per wave, a team
     of one workgroup) and on rows of 64..159 features (teams of 256-component workgroups): ragged / empty sessions,
