@@ -120,3 +120,65 @@ def test_gmm_ubm_and_ivector_experiments(tmp_path):
     acc_iv = float((cos.scoremat.argmax(0) == truth).mean())
     assert acc_iv >= 0.6, acc_iv
     print("accuracy: GMM-UBM %.2f, i-vector/cosine %.2f (chance %.2f)" % (acc_gmm, acc_iv, 1.0 / N_SPK))
+
+
+def test_reference_configuration_shape(tmp_path):
+    """BASELINE configs[0]: the conf.yaml UBM of the reference -- 64 diagonal components on 132-dimensional rows --
+    over isolated-word sessions (30 .. 220 frames, ragged, one empty).  The wide-row single-sweep kernels through the
+    drop-in classes: one EM iteration from the oracle's parameters, StatServer.accumulate_stat, two TV iterations
+    and extract_ivectors, each against the oracle on identical inputs."""
+    import sidekit_amd as sk
+    C, D, R = 64, 132, 20
+    rs = np.random.RandomState(7)
+    lens = [int(v) for v in rs.randint(30, 221, size=149)] + [0]
+    frames = orc.synth_frames(sum(lens), dim=D, clusters=48, seed=8)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    names = ["w%03d" % i for i in range(len(lens))]
+    sessions = [frames[off[i]:off[i + 1]] for i in range(len(lens))]
+    fs = sk.FeaturesServer(features=dict(zip(names, sessions)))
+    gmm = orc.random_gmm(C, D, seed=9)
+    ubm = sk.Mixture()
+    ubm.w, ubm.mu, ubm.invcov = gmm.w.copy(), gmm.mu.copy(), gmm.invcov.copy()
+    ubm.cov_var_ctl = 1.0 / ubm.invcov
+    ubm._compute_all()
+
+    # ---- one EM iteration (Mixture._expectation_list + _maximization, mixture.py:570-611) from identical parameters
+    import copy
+    accum = copy.deepcopy(ubm)
+    accum._reset()
+    llk_acc = np.zeros(1)
+    ubm._expectation_list(stat_acc=accum, feature_list=names[:-1], feature_server=fs, llk_acc=llk_acc, num_thread=1)
+    llk = llk_acc[0]
+    rN, rF, rS, rl = orc.expectation(gmm, frames.astype(np.float64))
+    assert np.abs(accum.w - rN).max() / rN.max() < 1e-4
+    assert np.abs(accum.mu - rF).max() / np.abs(rF).max() < 1e-4
+    assert np.abs(accum.invcov - rS).max() / np.abs(rS).max() < 1e-4
+    assert abs(llk - rl) < 1e-5 * abs(rl)
+
+    # ---- Baum-Welch statistics of the ragged sessions
+    idm = sk.IdMap().set(np.array(names), np.array(names))
+    ss = sk.StatServer(idm, ubm=ubm)
+    ss.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(len(names)))
+    s0, s1 = orc.accumulate_stat(gmm, [s.astype(np.float64) for s in sessions])
+    assert np.abs(ss.stat0 - s0).max() / np.abs(s0).max() < 1e-4
+    assert np.abs(ss.stat1 - s1).max() / np.abs(s1).max() < 1e-4
+    assert np.all(ss.stat0[-1] == 0) and np.all(ss.stat1[-1] == 0)
+    assert np.allclose(ss.stat0.sum(1), lens, rtol=1e-4)
+
+    # ---- total variability (2 iterations) and i-vectors from the reference-rounded statistics
+    stat_file = str(tmp_path / "stat.npz")
+    ss.write(stat_file)
+    back = sk.StatServer(stat_file)
+    tv_init = np.random.RandomState(10).randn(C * D, R)
+    fa = sk.FactorAnalyser()
+    fa.total_variability(stat_file, ubm, R, nb_iter=2, min_div=True, tv_init=tv_init.copy(), batch_size=50, num_thread=1)
+    rF_tv = orc.total_variability(back.stat0, back.stat1, gmm, R, nb_iter=2, min_div=True, tv_init=tv_init.copy(), batch_size=50)
+    rF_tv = rF_tv[0] if isinstance(rF_tv, tuple) else rF_tv
+    assert np.abs(fa.F - rF_tv).max() / np.abs(rF_tv).max() < 1e-4
+    ivs = fa.extract_ivectors(ubm, stat_file, batch_size=50)
+    r_iv = orc.extract_ivectors(back.stat0, back.stat1, gmm, fa.F, batch_size=50)
+    r_iv = r_iv[0] if isinstance(r_iv, tuple) else r_iv
+    live = np.array(lens) > 0
+    num = (ivs.stat1[live] * r_iv[live]).sum(1)
+    cos = num / (np.linalg.norm(ivs.stat1[live], axis=1) * np.linalg.norm(r_iv[live], axis=1))
+    assert cos.min() > 0.9999
