@@ -1949,7 +1949,7 @@ struct TeamArgs {
 // EM statistics: the team's tiles in one run, slabs folded every SKM_FLUSH_TILES tiles.  (k_seg_team below is
 // the same pipeline cut into segments with a flush per segment -- one session each -- for Baum-Welch; its
 // EM instantiation allocates registers worse than this dedicated kernel, 50 vs 36 ms at C=2048, so both stay.)
-template <int NCT, int NJT, int B, int GEO>
+template <int NCT, int NJT, int B, int GEO, bool GEN = (GEO < 0 && NJT <= 2)>   // GEN: rows of any length (TileStager)
 __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
 {
     constexpr int NF = 2 * NJT, NFW = NF * 32, PRE = (NJT >= 3) ? 20 : 8, RING = 4;   // PRE: see k_seg_team
@@ -2002,7 +2002,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
     bool dead = false;
     SKM_TRACE_DECL;
 
-    TileStager<PRE, (GEO < 0 && NJT <= 2)> stg;
+    TileStager<PRE, GEN> stg;
     stg.init(g, tid, nthr);
     if (ta < tb) {
         const long t0 = ta << 5;
@@ -2218,7 +2218,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
     }
 }
 
-template <int NCT, int NJT, int B, bool BW, int GEO>
+template <int NCT, int NJT, int B, bool BW, int GEO, bool GEN = (GEO < 0 && NJT <= 2)>
 __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
 {
     // PRE floats of a frame tile staged per thread: 32 * D <= PRE * 256 (rows of up to 160 floats at NJT >= 3)
@@ -2269,7 +2269,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
     unsigned n = 0;   // tiles this team has started: slot = n & 3, flag value = n + 1 (same on every member)
     SKM_TRACE_DECL;
 
-    TileStager<PRE, (GEO < 0 && NJT <= 2)> stg;
+    TileStager<PRE, GEN> stg;
     stg.init(g, tid, nthr);
     WSet<NCT> wa;
     wset_load<NCT>(wa, Wg4, g.NG, g.NP, 0);
@@ -3412,9 +3412,24 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
                 else if (p.team_B == 4) SKM_TEAM_LAUNCH(1, 4, -1);
                 else if (p.team_B == 8) SKM_TEAM_LAUNCH(1, 8, -1);
             } else if (!p.tg.vec4) {    // rows that are not a multiple of 16 bytes: the staging path for any D
-                if (p.team_B == 2) SKM_TEAM_LAUNCH(2, 2, -1);
-                else if (p.team_B == 4) SKM_TEAM_LAUNCH(2, 4, -1);
-                else if (p.team_B == 8) SKM_TEAM_LAUNCH(2, 8, -1);
+#define SKM_TEAMG_LAUNCH(B_, GEO_)                                                                                 \
+    do {                                                                                                          \
+        if ((rc = set_lds(k_estep_team<4, 2, B_, GEO_, true>, p.team_lds))) return rc;                            \
+        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_estep_team<4, 2, B_, GEO_, true>),       \
+                                        dim3(p.team_wgs), dim3(256), kargs, (unsigned)p.team_lds, st);            \
+    } while (0)
+#define SKM_TEAMG_GEO(B_)                                                                                          \
+    do {                                                                                                          \
+        if (geo == 0) SKM_TEAMG_LAUNCH(B_, 0);                                                                    \
+        else if (geo == 1) SKM_TEAMG_LAUNCH(B_, 1);                                                               \
+        else if (geo == 2) SKM_TEAMG_LAUNCH(B_, 2);                                                               \
+        else SKM_TEAMG_LAUNCH(B_, 3);                                                                             \
+    } while (0)
+                if (p.team_B == 2) SKM_TEAMG_GEO(2);
+                else if (p.team_B == 4) SKM_TEAMG_GEO(4);
+                else if (p.team_B == 8) SKM_TEAMG_GEO(8);
+#undef SKM_TEAMG_GEO
+#undef SKM_TEAMG_LAUNCH
             } else {
                 if (p.team_B == 2) SKM_TEAM_GEO(2);
                 else if (p.team_B == 4) SKM_TEAM_GEO(4);
@@ -3633,10 +3648,25 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
                 else if (p.team_B == 4) SKM_TEAM_LAUNCH(1, 4, -1);
                 else if (p.team_B == 8) SKM_TEAM_LAUNCH(1, 8, -1);
             } else if (!p.tg.vec4) {    // rows that are not a multiple of 16 bytes: the staging path for any D
-                if (p.team_B == 1) SKM_TEAM_LAUNCH(2, 1, -1);
-                else if (p.team_B == 2) SKM_TEAM_LAUNCH(2, 2, -1);
-                else if (p.team_B == 4) SKM_TEAM_LAUNCH(2, 4, -1);
-                else if (p.team_B == 8) SKM_TEAM_LAUNCH(2, 8, -1);
+#define SKM_TEAMG_LAUNCH(B_, GEO_)                                                                                 \
+    do {                                                                                                          \
+        if ((rc = set_lds(k_seg_team<4, 2, B_, true, GEO_, true>, p.team_lds))) return rc;                        \
+        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_seg_team<4, 2, B_, true, GEO_, true>),   \
+                                        dim3(p.team_wgs), dim3(256), kargs, (unsigned)p.team_lds, st);            \
+    } while (0)
+#define SKM_TEAMG_GEO(B_)                                                                                          \
+    do {                                                                                                          \
+        if (geo == 0) SKM_TEAMG_LAUNCH(B_, 0);                                                                    \
+        else if (geo == 1) SKM_TEAMG_LAUNCH(B_, 1);                                                               \
+        else if (geo == 2) SKM_TEAMG_LAUNCH(B_, 2);                                                               \
+        else SKM_TEAMG_LAUNCH(B_, 3);                                                                             \
+    } while (0)
+                if (p.team_B == 1) SKM_TEAMG_GEO(1);
+                else if (p.team_B == 2) SKM_TEAMG_GEO(2);
+                else if (p.team_B == 4) SKM_TEAMG_GEO(4);
+                else if (p.team_B == 8) SKM_TEAMG_GEO(8);
+#undef SKM_TEAMG_GEO
+#undef SKM_TEAMG_LAUNCH
             } else {
                 if (p.team_B == 1) SKM_TEAM_GEO(1);
                 else if (p.team_B == 2) SKM_TEAM_GEO(2);
