@@ -417,6 +417,9 @@ def main():
             host = X_all[:Sa * L].cpu().numpy()
             names = ["s%05d" % i for i in range(Sa)]
             fsa = sk.FeaturesServer(features={n: host[i * L:(i + 1) * L] for i, n in enumerate(names)})
+            ssw = sk.StatServer(sk.IdMap().set(names, names), ubm=ubm_b, engine=eng)       # warm-up: staging buffers exist
+            ssw.accumulate_stat(ubm=ubm_b, feature_server=fsa, seg_indices=range(min(Sa, 1100)), gather=False)
+            del ssw
             ssa = sk.StatServer(sk.IdMap().set(names, names), ubm=ubm_b, engine=eng)
             t0 = time.perf_counter()
             ssa.accumulate_stat(ubm=ubm_b, feature_server=fsa, seg_indices=range(Sa), gather=False)
@@ -714,6 +717,8 @@ def main():
                 ssh.stat1 = np.repeat(ssh.stat0, D, axis=1) * ubm_t.get_mean_super_vector() + rs.randn(Sa, Ct * D)
             tv0 = 0.1 * np.random.RandomState(7).randn(Ct * D, R)
             fa_api = sk.FactorAnalyser(engine=eng)
+            fa_api.total_variability_single(ssh, ubm_t, R, nb_iter=1, min_div=True, tv_init=tv0)     # warm-up: workspaces and
+            fa_api.extract_ivectors(ubm_t, ssh)                                                     # staging buffers exist
             t0 = time.perf_counter()
             fa_api.total_variability_single(ssh, ubm_t, R, nb_iter=1, min_div=True, tv_init=tv0)
             dt_a = time.perf_counter() - t0

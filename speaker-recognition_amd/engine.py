@@ -196,9 +196,12 @@ class HipEngine(object):
         if isinstance(x, torch.Tensor):
             t = x.to(device=self.device, dtype=torch.float32)
         else:
-            a = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+            a = np.asarray(x)
             if a.ndim == 1:
                 a = a[:, None]
+            if a.nbytes >= (32 << 20) and a.dtype in (np.float32, np.float64):
+                return self.upload_rows(a, dtype=torch.float32)      # pinned double buffers, rounding on the device
+            a = np.ascontiguousarray(a, dtype=np.float32)
             t = torch.from_numpy(a).to(self.device)
         return t.contiguous()
 
@@ -749,11 +752,81 @@ class HipEngine(object):
             if self._pin_up_used[j]:
                 self._pin_up_ev[j].synchronize()          # the transfer that last read this buffer is done
             buf = self._pin_up[j][:(r1 - r0) * w].view(r1 - r0, w)
-            buf.numpy()[...] = a[r0:r1]
+            self._host_copy(buf.numpy(), a[r0:r1])
             out[r0:r1].copy_(buf.to(self.device, non_blocking=True) if dtype != src_dtype else buf, non_blocking=True)
             self._pin_up_ev[j].record(st)
             self._pin_up_used[j] = True
         return out
+
+    def upload_sessions(self, sessions, chunk_bytes=64 << 20):
+        """The frames of a list of host sessions (each n_i x D, any float dtype) as ONE float32 device tensor
+        (sum n_i x D), in order.  Every session is copied (and converted) once, straight into one of two page-locked
+        staging buffers; full buffers go to the device asynchronously while the next one is filled.  Replaces
+        `upload_frames(np.concatenate(sessions))`: a pageable concatenation followed by a pageable transfer (0.8 s for
+        the 1.9 GB of 4000 sessions x 2000 frames on this box)."""
+        torch = self.torch
+        sessions = [np.asarray(x) for x in sessions]
+        sessions = [x[:, None] if x.ndim == 1 else x for x in sessions]
+        D = sessions[0].shape[1] if sessions else 0
+        T = int(sum(x.shape[0] for x in sessions))
+        out = torch.empty((T, D), dtype=torch.float32, device=self.device)
+        if T == 0 or D == 0:
+            return out
+        per = max(1, int(chunk_bytes // (D * 4)))              # rows per staging buffer
+        key = ("up", torch.float32, per * D)
+        if getattr(self, "_pin_up_key", None) != key:
+            self._pin_up = [torch.empty(per * D, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+            self._pin_up_ev = [torch.cuda.Event() for _ in range(2)]
+            self._pin_up_used = [False, False]
+            self._pin_up_key = key
+        st = torch.cuda.current_stream(self.device)
+        state = {"j": 0, "fill": 0, "done": 0}
+
+        def buffer():
+            j = state["j"]
+            if state["fill"] == 0 and self._pin_up_used[j]:
+                self._pin_up_ev[j].synchronize()              # the transfer that last read this buffer is done
+            return self._pin_up[j].numpy().reshape(per, D)
+
+        def send():
+            j, n = state["j"], state["fill"]
+            if n:
+                out[state["done"]:state["done"] + n].copy_(self._pin_up[j][:n * D].view(n, D), non_blocking=True)
+                self._pin_up_ev[j].record(st)
+                self._pin_up_used[j] = True
+                state["done"] += n
+                state["fill"] = 0
+                state["j"] = j ^ 1
+
+        for x in sessions:
+            assert x.shape[1] == D, "sessions of different dimensions"
+            r = 0
+            while r < x.shape[0]:
+                buf = buffer()
+                n = min(x.shape[0] - r, per - state["fill"])
+                buf[state["fill"]:state["fill"] + n] = x[r:r + n]      # numpy converts to float32 while copying
+                state["fill"] += n
+                r += n
+                if state["fill"] == per:
+                    send()
+        send()
+        return out
+
+    def _host_copy(self, dst, src, threads=4):
+        """dst[...] = src for two 2-D host arrays, the rows split over a few threads (numpy releases the GIL while it
+        copies; one core moves ~11 GB/s on this box, the pinned staging buffers arrive at 25+)."""
+        n = src.shape[0]
+        if n < 2 * threads or src.nbytes < (8 << 20):
+            dst[...] = src
+            return
+        if getattr(self, "_copy_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._copy_pool = ThreadPoolExecutor(max_workers=threads)
+        step = -(-n // threads)
+
+        def part(i):
+            dst[i:i + step] = src[i:i + step]
+        list(self._copy_pool.map(part, range(0, n, step)))
 
     def to_host_rows(self, t, out, rows=None, chunk_bytes=64 << 20):
         """out[rows] = t (a 2-D device tensor; rows None: out[:] = t) through two page-locked staging buffers: the copy
@@ -792,7 +865,7 @@ class HipEngine(object):
             self._pin_ev[k & 1].synchronize()
             src = pending.numpy()
             if rows is None:
-                out[a:b] = src
+                self._host_copy(out[a:b], src)
             else:
                 out[rows[a:b]] = src
             pending = nxt

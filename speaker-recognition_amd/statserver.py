@@ -235,7 +235,10 @@ class StatServer(object):
                 return
             lens = np.array([b.shape[0] for b in batch], dtype=np.int64)
             seg_off = np.concatenate([[0], np.cumsum(lens)])
-            X = eng.upload_frames(np.concatenate(batch, axis=0) if len(batch) > 1 else batch[0])
+            if hasattr(eng, "upload_sessions") and not any(type(b).__module__.startswith("torch") for b in batch):
+                X = eng.upload_sessions(batch)          # pinned, pipelined; no host concatenation
+            else:
+                X = eng.upload_frames(np.concatenate(batch, axis=0) if len(batch) > 1 else batch[0])
             s0, s1 = eng.bw_stats(X, seg_off, packed)
             store(batch_idx, s0, s1)
 
@@ -275,7 +278,9 @@ class StatServer(object):
                 cep = cep.detach().cpu().numpy()
             stop = vad.shape[0] if self.stop[idx] is None else min(self.stop[idx], vad.shape[0])
             data = cep[self.start[idx]:stop, :]
-            data = data[vad[self.start[idx]:stop], :]
+            sel = vad[self.start[idx]:stop]
+            if not sel.all():               # the reference's data[vad] copies even when every frame is kept
+                data = data[sel, :]
             if not ubm.dim() == data.shape[1]:
                 raise Exception('dimension of ubm and features differ: {:d} / {:d}'.format(ubm.dim(), data.shape[1]))
             batch.append(np.asarray(data, dtype=np.float32))
