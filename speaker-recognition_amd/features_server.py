@@ -238,6 +238,8 @@ class FeaturesServer(object):
         if self.has_post_processing():
             return self.load_batch(show_list)[0]
         blocks = [self.load(show)[0] for show in show_list]
+        if getattr(self, "_blocks_wanted", False):          # Mixture._resident_frames uploads the pieces itself
+            return blocks
         try:
             import torch
             if any(isinstance(b, torch.Tensor) for b in blocks):

@@ -257,6 +257,22 @@ class Mixture(object):
         count of a file without loading it (`frame_counts`) lets every rank load only the files that overlap its
         row range instead of stacking everything on every host."""
         if not dist.is_dist() or getattr(features_server, "is_sharded", False):
+            # host files go straight into the pinned staging buffers (engine.upload_sessions): no np.vstack of the
+            # whole training set in pageable memory in front of the transfer
+            if hasattr(self.engine, "upload_sessions") and hasattr(features_server, "has_post_processing") \
+                    and not features_server.has_post_processing():
+                features_server._blocks_wanted = True
+                try:
+                    blocks = features_server.stack_features_parallel(feature_list, num_thread=1)
+                finally:
+                    features_server._blocks_wanted = False
+                if isinstance(blocks, list) and blocks and all(isinstance(b, np.ndarray) for b in blocks):
+                    return self.engine.upload_sessions(blocks)
+                if isinstance(blocks, list):
+                    torch = self.engine.torch
+                    blocks = [self._device_frames(b) for b in blocks]
+                    return torch.cat(blocks, dim=0) if len(blocks) > 1 else blocks[0]
+                return self._device_frames(blocks)
             return self._device_frames(features_server.stack_features_parallel(feature_list, num_thread=1))
         feature_list = list(feature_list)
         counts = features_server.frame_counts(feature_list) if hasattr(features_server, "frame_counts") else None
