@@ -679,7 +679,7 @@ __device__ __forceinline__ TO slide_value(double x, double pivot, double sum, do
     }
     float var = (float)((ssq - sum * sum * inv_w) * (1.0 / (w - 1.0)));
     if (var < 0.f) var = 0.f;
-    return (TO)((float)v / __fsqrt_rn(var));
+    return (TO)((float)v * __builtin_amdgcn_rsqf(var));     // v_rsq_f32 (1 ulp) instead of sqrt + divide (~20 instructions)
 }
 
 template <typename TI, typename TO>
@@ -795,28 +795,39 @@ __global__ __launch_bounds__(256) void k_feat_sliding_lds(const TI *__restrict__
     __syncthreads();
     const long a = p0 + (long)sub * SL, b = (a + SL < p1) ? a + SL : p1;
     if (a >= b || !col_ok) return;
-    const TI *tc = tile + col - qa * FEAT_SB;                // tc[q * FEAT_SB] = value of labelled frame q
+    // positions relative to the first row of the tile, 32-bit: the slide loop was 122 vector instructions per output,
+    // a third of them 64-bit index arithmetic (PMC: SQ_INSTS_VALU 8.0e8 per launch, LDS bank conflicts < 1 %)
+    const TI *tc = tile + col;                               // tc[r * FEAT_SB] = value of row r of the tile
+    const int ra = (int)(a - qa), rb = (int)(b - qa), idw = (int)dw;
+    const int c_lo = (int)(dw - qa), c_hi = (int)(n - dw - 1 - qa);     // centre(p) - qa = clamp(p - qa, c_lo, c_hi)
+    auto centre_r = [&](int r) { return r < c_lo ? c_lo : (r > c_hi ? c_hi : r); };
     const double w = (double)win, inv_w = 1.0 / w;
-    long c = centre(a);
-    const double pivot = (double)tc[(c - dw) * FEAT_SB];
+    int c = centre_r(ra);
+    const double pivot = (double)tc[(c - idw) * FEAT_SB];
     double sum = 0.0, ssq = 0.0;
 #pragma unroll 8
-    for (long q = c - dw; q <= c + dw; ++q) {
+    for (int q = c - idw; q <= c + idw; ++q) {
         const double v = (double)tc[q * FEAT_SB] - pivot;
         sum += v;
         ssq += v * v;
     }
-    for (long p = a; p < b; ++p) {
-        const long cn = centre(p);
+    TO *orow = out + (coff[s] + a) * D + j0 + col;          // compact: consecutive labelled frames, consecutive rows
+    for (int r = ra; r < rb; ++r) {
+        const int cn = centre_r(r);
         if (cn != c) {      // the window moves by one labelled frame
-            const double vin = (double)tc[(cn + dw) * FEAT_SB] - pivot;
-            const double vout = (double)tc[(c - dw) * FEAT_SB] - pivot;
+            const double vin = (double)tc[(cn + idw) * FEAT_SB] - pivot;
+            const double vout = (double)tc[(c - idw) * FEAT_SB] - pivot;
             sum += vin - vout;
             ssq += vin * vin - vout * vout;
             c = cn;
         }
-        out[(compact ? coff[s] + p : ix[p]) * D + j0 + col] =
-            slide_value<TO>((double)tc[p * FEAT_SB], pivot, sum, ssq, w, inv_w, reduce);
+        const TO o = slide_value<TO>((double)tc[r * FEAT_SB], pivot, sum, ssq, w, inv_w, reduce);
+        if (compact) {
+            *orow = o;
+            orow += D;
+        } else {
+            out[(long)rown[r] * D + j0 + col] = o;
+        }
     }
 }
 
