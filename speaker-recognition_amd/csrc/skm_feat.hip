@@ -235,7 +235,7 @@ struct FeatStep {
 // chain of dependent steps would otherwise expose the memory latency once per frame), and 7 steps per block make
 // the ring positions compile-time constants.
 template <int NDELTA, int RASTA, int MODE, int IN64, int OUT64>
-__global__ __launch_bounds__(256) void k_feat_walk(
+__global__ __launch_bounds__(256, 4) void k_feat_walk(
     const void *__restrict__ X, long ldx, const int *__restrict__ cols,
     const uint8_t *__restrict__ lab, const int64_t *__restrict__ seg_off, const int64_t *__restrict__ chunk_base,
     int S, int D0, long items_max, FeatFilt ff, const double *__restrict__ E,
