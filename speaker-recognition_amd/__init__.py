@@ -2,7 +2,7 @@
 method surface of sidekit.{Mixture, StatServer, FactorAnalyser} (reference: Anwarvic/Speaker-Recognition,
 a SIDEKIT 1.3.2 fork).  Import through the repo-root shim:  `import sidekit_amd as sidekit`."""
 from .engine import HipEngine, SkmError, default_engine, set_default_engine, load_library, LIB_PATH  # noqa: F401
-from .idmap import IdMap, Ndx, Scores  # noqa: F401
+from .idmap import IdMap, Ndx, Scores, Key  # noqa: F401
 from .features_server import FeaturesServer  # noqa: F401
 from .mixture import Mixture  # noqa: F401
 from .statserver import StatServer  # noqa: F401

@@ -295,3 +295,104 @@ class Scores(object):
         sub_mask[rr, cc] = self.scoremask[rows[rr], cols[cc]]
         sub[rr, cc] = self.scoremat[rows[rr], cols[cc]]
         return sub[np.asarray(key.tar, bool) & sub_mask], sub[np.asarray(key.non, bool) & sub_mask]
+
+
+class Key(object):
+    """Trial key (sidekit/bosaris/key.py:49-107): modelset [M], segset [N], tar / non [M x N] bool -- which trials are
+    target and which are non-target trials; what Scores.get_tar_non splits a score matrix with."""
+
+    def __init__(self, key_file_name='', models=np.array([]), testsegs=np.array([]), trials=np.array([])):
+        self.modelset = np.empty(0, dtype="|O")
+        self.segset = np.empty(0, dtype="|O")
+        self.tar = np.array([], dtype="bool")
+        self.non = np.array([], dtype="bool")
+        if key_file_name != '':
+            tmp = Key.read(key_file_name)
+            self.modelset, self.segset, self.tar, self.non = tmp.modelset, tmp.segset, tmp.tar, tmp.non
+            return
+        models, testsegs, trials = np.asarray(models), np.asarray(testsegs), np.asarray(trials)
+        self._from_lists(models, testsegs, trials)
+
+    def _from_lists(self, models, testsegs, trials):
+        """One (model, segment, 'target' | 'nontarget') triple per trial (key.py:78-98); the last triple of a pair wins."""
+        self.modelset, mi = np.unique(models, return_inverse=True)
+        self.segset, si = np.unique(testsegs, return_inverse=True)
+        self.tar = np.zeros((self.modelset.shape[0], self.segset.shape[0]), dtype="bool")
+        self.non = np.zeros((self.modelset.shape[0], self.segset.shape[0]), dtype="bool")
+        if models.shape[0]:
+            self.tar[mi, si] = (trials == 'target')          # later assignments overwrite earlier ones, as the dict does
+            self.non[mi, si] = (trials == 'nontarget')
+        assert self.validate(), "Wrong Key format"
+
+    def validate(self):
+        """key.py:199-216."""
+        return bool(isinstance(self.modelset, np.ndarray) and isinstance(self.segset, np.ndarray)
+                    and isinstance(self.tar, np.ndarray) and isinstance(self.non, np.ndarray)
+                    and self.modelset.ndim == 1 and self.segset.ndim == 1 and self.tar.ndim == 2 and self.non.ndim == 2
+                    and self.tar.shape == self.non.shape
+                    and self.tar.shape == (self.modelset.shape[0], self.segset.shape[0]))
+
+    def to_ndx(self):
+        """key.py:188-197."""
+        ndx = Ndx()
+        ndx.modelset, ndx.segset, ndx.trialmask = self.modelset, self.segset, self.tar | self.non
+        return ndx
+
+    def filter(self, modlist, seglist, keep):
+        """key.py:147-186."""
+        km, ks = np.isin(self.modelset, np.asarray(modlist)), np.isin(self.segset, np.asarray(seglist))
+        if not keep:
+            km, ks = ~km, ~ks
+        out = Key()
+        out.modelset, out.segset = self.modelset[km], self.segset[ks]
+        out.tar, out.non = self.tar[km, :][:, ks], self.non[km, :][:, ks]
+        assert out.validate(), "Wrong Key format"
+        return out
+
+    def write(self, output_file_name):
+        """`.h5`: modelset, segset, trial_mask = tar - non as int8 (key.py:109-129); any other name: .npz."""
+        assert self.validate(), "Error: wrong Key format"
+        mask = self.tar.astype('int8') - self.non.astype('int8')
+        if _is_h5(output_file_name):
+            with _h5().File(output_file_name, "w") as f:
+                f.create_dataset("modelset", data=np.asarray(self.modelset).astype('S'), maxshape=(None,),
+                                 compression="gzip", fletcher32=True)
+                f.create_dataset("segset", data=np.asarray(self.segset).astype('S'), maxshape=(None,),
+                                 compression="gzip", fletcher32=True)
+                f.create_dataset("trial_mask", data=mask, maxshape=(None, None), compression="gzip", fletcher32=True)
+            return
+        np.savez(output_file_name, modelset=np.asarray(self.modelset).astype('U'),
+                 segset=np.asarray(self.segset).astype('U'), trial_mask=mask)
+
+    def write_txt(self, output_file_name):
+        """key.py:132-145: `model segment target|nontarget` per trial."""
+        with open(output_file_name, 'w') as fh:
+            for m in range(self.modelset.shape[0]):
+                for s in self.segset[self.tar[m, ]]:
+                    fh.write('{} {} {}\n'.format(self.modelset[m], s, 'target'))
+                for s in self.segset[self.non[m, ]]:
+                    fh.write('{} {} {}\n'.format(self.modelset[m], s, 'nontarget'))
+
+    @staticmethod
+    def read(input_file_name):
+        """key.py:219-240."""
+        key = Key()
+        if _is_h5(input_file_name):
+            with _h5().File(input_file_name, "r") as f:
+                key.modelset, key.segset = _h5_ids(f, "modelset", 100), _h5_ids(f, "segset", 100)
+                mask = np.asarray(f["trial_mask"][()])
+        else:
+            z = np.load(input_file_name, allow_pickle=False)
+            key.modelset, key.segset, mask = z["modelset"], z["segset"], z["trial_mask"]
+        key.tar, key.non = (mask == 1), (mask == -1)
+        assert key.validate(), "Error: wrong Key format"
+        return key
+
+    @staticmethod
+    def read_txt(input_file_name):
+        """key.py:243-284."""
+        with open(input_file_name, 'r') as fh:
+            rows = [l.split() for l in fh if l.strip()]
+        key = Key()
+        key._from_lists(np.array([r[0] for r in rows]), np.array([r[1] for r in rows]), np.array([r[2] for r in rows]))
+        return key

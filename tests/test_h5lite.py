@@ -222,3 +222,38 @@ def test_bosaris_text_files(tmp_path):
         non = np.array([[True, False], [False, True]])
     tar, non = back.get_tar_non(Key)
     assert sorted(tar) == [-2.25, 0.125] and list(non) == [1.5]     # (m2, s3) was never scored
+
+
+@pytest.mark.parametrize("ext", [".h5", ".npz", ".txt"])
+def test_key_files_and_score_split(tmp_path, ext):
+    """The BOSARIS Key (key.py:49-284): built from trial lists, written / read in the reference's datasets, turned
+    into an Ndx, and used to split a Scores matrix into target and non-target scores."""
+    models = np.array(["m2", "m1", "m1", "m2", "m1"])
+    segs = np.array(["s1", "s1", "s3", "s3", "s2"])
+    trials = np.array(["nontarget", "target", "nontarget", "target", "target"])
+    key = sk.Key(models=models, testsegs=segs, trials=trials)
+    assert list(key.modelset) == ["m1", "m2"] and list(key.segset) == ["s1", "s2", "s3"]
+    assert np.array_equal(key.tar, [[True, True, False], [False, False, True]])
+    assert np.array_equal(key.non, [[False, False, True], [True, False, False]])
+    p = str(tmp_path / ("key" + ext))
+    if ext == ".txt":
+        key.write_txt(p)
+        back = sk.Key.read_txt(p)
+    else:
+        key.write(p)
+        back = sk.Key.read(p)
+        assert np.array_equal(sk.Key(p).tar, key.tar)
+    assert list(back.modelset) == ["m1", "m2"] and np.array_equal(back.tar, key.tar) and np.array_equal(back.non, key.non)
+    if ext == ".h5":
+        with sk.h5lite.File(p, "r") as f:
+            assert np.array_equal(f["trial_mask"][()], [[1, 1, -1], [-1, 0, 1]]) and f["trial_mask"][()].dtype == np.int8
+    ndx = key.to_ndx()
+    assert np.array_equal(ndx.trialmask, [[True, True, True], [True, False, True]])
+    sub = key.filter(["m1"], ["s1", "s3"], keep=True)
+    assert list(sub.modelset) == ["m1"] and np.array_equal(sub.tar, [[True, False]]) and np.array_equal(sub.non, [[False, True]])
+    sc = sk.Scores()
+    sc.modelset, sc.segset = key.modelset, key.segset
+    sc.scoremask = ndx.trialmask.copy()
+    sc.scoremat = np.array([[3.0, 2.0, -1.0], [-2.0, 9.0, 4.0]])
+    tar, non = sc.get_tar_non(key)
+    assert sorted(tar) == [2.0, 3.0, 4.0] and sorted(non) == [-2.0, -1.0]
