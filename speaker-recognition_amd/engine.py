@@ -758,6 +758,12 @@ class HipEngine(object):
             self._pin_up_used[j] = True
         return out
 
+    def copy_stream(self):
+        """A second stream of this device for transfers that must overlap the kernels (StatServer.accumulate_stat)."""
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = self.torch.cuda.Stream(device=self.device)
+        return self._copy_stream
+
     def upload_sessions(self, sessions, chunk_bytes=64 << 20):
         """The frames of a list of host sessions (each n_i x D, any float dtype) as ONE float32 device tensor
         (sum n_i x D), in order.  Every session is copied (and converted) once, straight into one of two page-locked

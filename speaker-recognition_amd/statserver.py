@@ -218,15 +218,47 @@ class StatServer(object):
         C, D = ubm.distrib_nb(), ubm.dim()
         kept = []                         # (rows, stat0 f32, stat1 f32) device blocks when keep_on_device
 
+        # The copy off the device is a pipeline stage of its own: a worker thread drains finished batches on a second
+        # stream (engine.to_host_rows: pinned double buffers + threaded host copy) while this thread uploads and
+        # launches the next batch.  Host float64 statistics are 2 KB per frame at C = 2048: the API is bound by that
+        # transfer, so it must never wait behind, or make wait, the kernels.
+        pipelined = hasattr(eng, "to_host_rows") and hasattr(eng, "copy_stream") and str(eng.device).startswith("cuda")
+        pending = []
+        if pipelined:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=1)
+            cstream = eng.copy_stream()
+
+        def drain(rows, s0, s1, ready):
+            with torch.cuda.stream(cstream):
+                cstream.wait_event(ready)
+                eng.to_host_rows(s0, self.stat0, rows)
+                eng.to_host_rows(s1, self.stat1, rows)
+                cstream.synchronize()
+
         def store(rows, s0, s1):
-            if hasattr(eng, "to_host_rows"):        # pinned, pipelined copy off the device (engine.to_host_rows)
+            if keep_on_device:
+                kept.append((list(rows), s0.to(torch.float32), s1.to(torch.float32)))
+            if pipelined:
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(eng.device))
+                s0.record_stream(cstream)
+                s1.record_stream(cstream)
+                while len(pending) >= 2:                    # at most two batches of statistics wait in HBM
+                    pending.pop(0).result()
+                pending.append(pool.submit(drain, list(rows), s0, s1, ready))
+            elif hasattr(eng, "to_host_rows"):      # pinned, pipelined copy off the device (engine.to_host_rows)
                 eng.to_host_rows(s0, self.stat0, rows)
                 eng.to_host_rows(s1, self.stat1, rows)
             else:
                 self.stat0[rows, :] = eng.to_host(s0)
                 self.stat1[rows, :] = eng.to_host(s1)
-            if keep_on_device:
-                kept.append((list(rows), s0.to(torch.float32), s1.to(torch.float32)))
+
+        def finish_stores():
+            while pending:
+                pending.pop(0).result()                     # re-raises what the worker raised
+            if pipelined:
+                pool.shutdown()
 
         batch, batch_idx, nframes = [], [], 0
 
@@ -286,10 +318,11 @@ class StatServer(object):
             batch.append(np.asarray(data, dtype=np.float32))
             batch_idx.append(idx)
             nframes += data.shape[0]
-            if nframes >= max_batch_frames:
-                run_batch()
+            if nframes >= (min(max_batch_frames, 1 << 20) if pipelined else max_batch_frames):
+                run_batch()             # pipelined: batches of about a million frames keep all three stages busy
                 batch, batch_idx, nframes = [], [], 0
         run_batch()
+        finish_stores()
 
         if keep_on_device and kept:
             rows = [r for blk in kept for r in blk[0]]
