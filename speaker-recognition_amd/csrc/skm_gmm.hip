@@ -1850,6 +1850,10 @@ __device__ __forceinline__ void flush_session_agpr(f32x16 (&acc)[NCT][NF], doubl
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
+            // the next asm MFMA on this tile may follow at once (a session that ends inside a tile: flush, then the rest of
+            // the tile): a vector write of the accumulator needs wait states before an MFMA reads it as its C operand, and
+            // the compiler places none in front of asm (it also may sink the sixteen writes right in front of that asm)
+            asm volatile("s_nop 3" : "+a"(acc[ct][jf]));
             __builtin_amdgcn_sched_barrier(0);
         }
 }
@@ -2218,6 +2222,40 @@ __global__ __launch_bounds__(256, 1) void k_estep_team(TeamArgs a)
     }
 }
 
+// Baum-Welch statistics of the frames [lo, hi) of a tile only (a tile that holds the end of one session and the start
+// of the next): the B operand -- lane (c, h) holds x[acc_row(r, h)][c] at step r -- is zeroed outside the range, gamma
+// stays as it is.  No S accumulators.
+template <int NJT, int NCT>
+__device__ __forceinline__ void gemm_stats_agpr_masked(f32x16 (&acc)[NCT][NJT], const f32x16 (&lg)[NCT], const float *xcol,
+                                                       int XS, int lo, int hi, int h)
+{
+    float bn[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) bn[jt] = xcol[jt * 32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int fr = acc_row(r, 0) + 4 * h;
+        const bool in = fr >= lo && fr < hi;
+        float b[NJT];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) b[jt] = in ? bn[jt] : 0.f;
+        if (r < 15) {
+            const float *xrow = xcol + acc_row(r + 1, 0) * XS;
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) bn[jt] = xrow[jt * 32];
+        }
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                if (ct == 0)
+                    mfma_agpr_after_valu(acc[ct][jt], lg[ct][r], b[jt]);
+                else
+                    mfma_agpr(acc[ct][jt], lg[ct][r], b[jt]);
+            }
+    }
+}
+
 template <int NCT, int NJT, int B, bool BW, int GEO, bool GEN = (GEO < 0 && NJT <= 2)>
 __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
 {
@@ -2315,8 +2353,18 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
         if (lane == 0 && !muted)
             __hip_atomic_store(flags + flag_slot * NC + me, flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    // The tile loop is left and re-entered at session ends, and the instantiations with few free registers spill: whatever
+    // copy or spill of an accumulator the compiler places behind a statistics GEMM must not read it while the last asm
+    // MFMA is in flight (the hazard recogniser cannot see inside asm)
+    auto settle_acc = [&]() __attribute__((always_inline)) {
+        asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0][0]));
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int jf = 0; jf < NF; ++jf) asm volatile("" : "+a"(acc[ct][jf]));
+    };
     auto finish_tile = [&](f32x16 (&lg)[NCT], unsigned ni, int nvalid, long t_pf, int nv_pf, int flag_slot,
-                           unsigned flag_val) __attribute__((always_inline)) {
+                           unsigned flag_val, int hi_first = 32) __attribute__((always_inline)) {
         float mx = -3.0e38f, sum = 0.f, m_me = 0.f;
         {
 #pragma unroll
@@ -2361,7 +2409,12 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
         for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
         const float *xt = xs + (int)(ni & (RING - 1)) * tile_floats;
         SKM_STAMP(5);
-        gemm_stats_agpr<NJT, NCT, !BW>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
+        if constexpr (BW) {     // the frames [0, hi_first) of the tile: the whole tile unless a session ends inside it
+            gemm_stats_agpr_masked<NJT, NCT>(acc, lg, xt + 4 * h * g.XS + c, g.XS, 0, hi_first, h);
+            settle_acc();
+        } else {
+            gemm_stats_agpr<NJT, NCT, true>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
+        }
         wave_lds_fence();
     };
 
@@ -2476,6 +2529,162 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
         n += (unsigned)ntile;
     };
 
+    // Baum-Welch: the team walks the frames of its sessions as ONE stream of 32-frame tiles (no pipeline fill / drain and
+    // no partial tile per session).  The tile loop is the EM loop; it is LEFT when the tile it has just finished holds the
+    // end of a session (finish_tile took only that session's frames of the tile): the session's float64 rows are written
+    // out here, outside the loop -- with the flush inside the loop hipcc shuffled the 128 accumulator registers at every
+    // merge --, the rest of the tile goes to the next session(s) through the same masked GEMM, and the loop resumes.
+    int cur_s = 0, cur_end_s = 0, acc_tiles = 0;
+    long cur_e = 0;
+    bool cur_add = false;
+    auto close_rows = [&](bool add) __attribute__((always_inline)) {
+        flush_session_agpr<NCT, NF>(acc, a.stat0 + (long)cur_s * a.C, a.stat1 + (long)cur_s * a.C * g.D, me, g.D, lane, add,
+                                    a.C);
+    };
+    // after finish_tile(…, hi_first) of a tile [t0, t0 + nvalid) in which the current session ends at hi_first
+    auto close_boundary = [&](f32x16 (&lg)[NCT], unsigned ni, long t0, int nvalid, int hi_first) __attribute__((always_inline)) {
+        const float *xt = xs + (int)(ni & (RING - 1)) * tile_floats;
+        int lo = hi_first;
+        close_rows(cur_add);
+        cur_add = false;
+        acc_tiles = 0;
+        ++cur_s;
+        if (cur_s < cur_end_s) cur_e = a.seg_off[cur_s + 1];
+#pragma unroll 1
+        while (lo < nvalid || (cur_s < cur_end_s && cur_e - t0 <= (long)nvalid)) {
+            const bool ends = cur_s < cur_end_s && cur_e - t0 <= (long)nvalid;
+            const int hi = ends ? (int)(cur_e - t0) : 32;
+            if constexpr (BW) {
+                if (hi > lo) {
+                    gemm_stats_agpr_masked<NJT, NCT>(acc, lg, xt + 4 * h * g.XS + c, g.XS, lo, hi, h);
+                    settle_acc();
+                }
+            }
+            if (!ends) {
+                acc_tiles = 1;
+                break;
+            }
+            close_rows(false);
+            lo = hi;
+            ++cur_s;
+            if (cur_s < cur_end_s) cur_e = a.seg_off[cur_s + 1];
+        }
+    };
+    auto run_stream = [&](long b, long e) __attribute__((always_inline)) {
+        const int ntile = (int)((e - b + 31) >> 5);
+        if (ntile == 0) return;
+        auto nv = [&](int i) __attribute__((always_inline)) {
+            const long left = e - (b + 32L * i);
+            return (int)(left < 32 ? left : 32);
+        };
+        // frames of the current session inside tile j (32: the session goes on beyond the tile)
+        auto first_piece = [&](int j) __attribute__((always_inline)) {
+            const long left = cur_e - (b + 32L * j);
+            return (int)(left <= (long)nv(j) ? left : 32);
+        };
+        stg.load(a.X, b, nv(0), g.D);
+        stg.store(xs + (int)(n & (RING - 1)) * tile_floats);
+        if (ntile > 1) stg.load(a.X, b + 32, nv(1), g.D);
+        __syncthreads();
+        f32x16 lg[NCT];
+        int i = 0;
+#pragma unroll 1
+        while (i < ntile) {
+            int stop = 0, hi_first = 32;      // 1: a session ended in tile i - 1, 2: fold of a long session
+#pragma unroll 1
+            for (; i < ntile && !stop; ++i) {
+                const unsigned ni = n + (unsigned)i;
+                const int cur = (int)(ni & (RING - 1)), nxt = (cur + 1) & (RING - 1), slot = (int)(ni & 3);
+                const float *xt = xs + cur * tile_floats;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int jf = 0; jf < NF; ++jf) asm volatile("" : "+a"(acc[ct][jf]));
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    float k = kcv[ct];
+                    asm volatile("" : "+v"(k));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lg[ct][r] = k;
+                }
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
+                gemm_logits_fat<NCT, GEO>(lg, wa, xt + c * g.XS, h, Wg4, g);
+                if (i > 0) poll_issue(ni - 1);
+                float m[16];
+                tile_row_max<NCT>(lg, m);
+                lane_reduce16(m, c, OpMaxHw());
+                const int frame = acc_row((c >> 1) & 15, h);
+                if ((c & 1) == 0) ls[frame] = m[0];
+                wave_lds_fence();
+                float sm[16];
+                tile_exp_sum<NCT>(lg, ls + 4 * h, sm);
+                lane_reduce16(sm, c, OpAdd());
+                if ((c & 1) == 0) {
+                    unsigned long long *row = reinterpret_cast<unsigned long long *>(xch) + ((long)slot * NC + me) * 32 + frame;
+                    const unsigned long long pr = (unsigned long long)__builtin_bit_cast(unsigned, m[0]) |
+                                                  ((unsigned long long)__builtin_bit_cast(unsigned, sm[0]) << 32);
+                    __hip_atomic_store(row, pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                        if (i > 0) o = stash[(ct * 4 + q) * 64];
+                        const f32x4 nw = {lg[ct][4 * q], lg[ct][4 * q + 1], lg[ct][4 * q + 2], lg[ct][4 * q + 3]};
+                        stash[(ct * 4 + q) * 64] = nw;
+                        lg[ct][4 * q] = o[0];
+                        lg[ct][4 * q + 1] = o[1];
+                        lg[ct][4 * q + 2] = o[2];
+                        lg[ct][4 * q + 3] = o[3];
+                    }
+                if (i + 1 < ntile) stg.store(xs + nxt * tile_floats);
+                if (i == 0 && ntile > 2) stg.load(a.X, b + 64, nv(2), g.D);
+                const bool early_flag = i == 0 || i + 1 == ntile;
+                if (early_flag) publish_flag(slot, ni + 1u);
+                if (i > 0) collect(ni - 1);
+                __syncthreads();
+                if (i > 0) {
+                    hi_first = first_piece(i - 1);
+                    finish_tile(lg, ni - 1, nv(i - 1), (i + 2 < ntile) ? b + 32L * (i + 2) : -1L,
+                                (i + 2 < ntile) ? nv(i + 2) : 0, slot, early_flag ? 0u : ni + 1u, hi_first);
+                    if (hi_first < 32 || (long)hi_first == cur_e - (b + 32L * (i - 1)))
+                        stop = 1;
+                    else if (++acc_tiles >= SKM_FLUSH_TILES)
+                        stop = 2;
+                }
+            }
+            if (stop == 1) {
+                close_boundary(lg, n + (unsigned)i - 2u, b + 32L * (i - 2), nv(i - 2), hi_first);
+            } else if (stop == 2) {         // long session: fold into its float64 rows like the EM slabs
+                close_rows(cur_add);
+                cur_add = true;
+                acc_tiles = 0;
+            }
+        }
+        {   // drain: the last tile of the stream (the team's last session ends in it)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 o = stash[(ct * 4 + q) * 64];
+                    lg[ct][4 * q] = o[0];
+                    lg[ct][4 * q + 1] = o[1];
+                    lg[ct][4 * q + 2] = o[2];
+                    lg[ct][4 * q + 3] = o[3];
+                }
+            const unsigned nl = n + (unsigned)ntile - 1u;
+            poll_issue(nl);
+            collect(nl);
+            const int hi_last = first_piece(ntile - 1);
+            finish_tile(lg, nl, nv(ntile - 1), -1L, 0, 0, 0u, hi_last);
+            close_boundary(lg, nl, b + 32L * (ntile - 1), nv(ntile - 1), hi_last);
+        }
+        n += (unsigned)ntile;
+    };
+
     if (!BW) {
         const long tiles = (a.T + 31) >> 5;
         const long fa = (tiles * team / n_teams) << 5;
@@ -2507,21 +2716,14 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
         };
         const int sa = (team == 0) ? 0 : lower(total * team / n_teams);
         const int sb = (team == n_teams - 1) ? a.S : lower(total * (team + 1) / n_teams);
-        // a session longer than SKM_FLUSH_TILES tiles is run in pieces and its f32 accumulators are folded into
-        // the float64 output rows after each piece (first fold stores, later ones add), like the EM slabs
-#pragma unroll 1
-        for (int sidx = sa; sidx < sb; ++sidx) {
-            const long sb0 = so[sidx], se0 = so[sidx + 1];
-            long pb = sb0;
-#pragma unroll 1
-            do {
-                const long pe = (pb + 32L * SKM_FLUSH_TILES < se0) ? pb + 32L * SKM_FLUSH_TILES : se0;
-                run_segment(pb, pe);
-                flush_session_agpr<NCT, NF>(acc, a.stat0 + (long)sidx * a.C, a.stat1 + (long)sidx * a.C * g.D, me, g.D,
-                                            lane, pb > sb0, a.C);
-                pb = pe;
-            } while (pb < se0);
+        cur_s = sa;
+        cur_end_s = sb;
+        cur_e = (sa < sb) ? so[sa + 1] : 0;
+        if constexpr (BW) {
+            if (sa < sb) run_stream(so[sa], so[sb]);
         }
+#pragma unroll 1
+        for (; cur_s < sb; ++cur_s) close_rows(false);      // no frame at all in the team's range: empty sessions read zero
     }
 }
 
