@@ -7,6 +7,9 @@ CS="$ROOT/speaker-recognition_amd/csrc"
 name="$1"; shift
 mkdir -p "$ROOT/tools/ab"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" "$@" -c "$CS/skm_gmm.hip" -o "$ROOT/tools/ab/skm_gmm_$name.o"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$ROOT/tools/ab/skm_gmm_$name.o" "$CS/obj/skm_backend.o" "$CS/obj/skm_feat.o" "$CS/obj/skm_gemm.o" "$CS/obj/skm_tv.o" -o "$ROOT/tools/ab/libskm_$name.so"
+# every other object of the in-tree build is reused (the team / segment kernels live in their own translation units:
+# a flag that changes THEM needs those recompiled too)
+others=$(ls "$CS"/obj/*.o | grep -v "/skm_gmm.o$")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$ROOT/tools/ab/skm_gmm_$name.o" $others -o "$ROOT/tools/ab/libskm_$name.so"
 rm -f "$ROOT/tools/ab/skm_gmm_$name.o"
 echo "built tools/ab/libskm_$name.so"
