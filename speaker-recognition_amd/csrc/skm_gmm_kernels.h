@@ -568,24 +568,26 @@ __device__ __forceinline__ void stats_tile(f32x16 (&acc)[NCT][NJT * (WITH_S ? 2 
     if (lane < 32) ls[lane] = (lane < nvalid) ? lse2[t0 + lane] : 3.0e38f;
     wave_lds_fence();
 
+    // The logits are accumulated exactly as in sweep 1 (same start value, same order: the same bits), and the
+    // row's log-sum-exp is taken off afterwards.  Starting the accumulator at kc - lse instead saves 16 * NCT
+    // subtractions but rounds every step of the chain differently from the sweep that made lse: the posteriors
+    // of a frame then miss sum 1 by the accumulation error of a logit (4e-5 at 156 columns, 6e-6 at 60).
     f32x16 lg[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lg[ct][r] = kcv[ct];
+    gemm_logits<NCT>(lg, xs + c * g.XS, h, Wl4, g);
+
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
         const f32x4 l4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            lg[ct][4 * q4 + 0] = kcv[ct] - l4[0];
-            lg[ct][4 * q4 + 1] = kcv[ct] - l4[1];
-            lg[ct][4 * q4 + 2] = kcv[ct] - l4[2];
-            lg[ct][4 * q4 + 3] = kcv[ct] - l4[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lg[ct][4 * q4 + i] = __builtin_amdgcn_exp2f(lg[ct][4 * q4 + i] - l4[i]);
         }
     }
-    gemm_logits<NCT>(lg, xs + c * g.XS, h, Wl4, g);
-
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) lg[ct][r] = __builtin_amdgcn_exp2f(lg[ct][r]);
 
     gemm_stats<NJT, NCT, WITH_S>(acc, lg, xs + 4 * h * g.XS + c, g.XS);
     wave_lds_fence();  // every read of xs retired (in order) before the next tile is staged

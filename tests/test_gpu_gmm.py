@@ -248,6 +248,28 @@ def test_bw_stats_small_blocks_and_wide_rows(eng, C, D):
     assert ("k_bw_team" in prof) == (not (C == 17)), prof
 
 
+@pytest.mark.parametrize("C,D", [(2, 156), (16, 132), (100, 159), (256, 159), (1500, 156), (64, 60), (300, 60),   # two sweeps
+                                 (64, 132), (512, 132), (512, 60), (2048, 60), (128, 39)])                         # one kernel
+def test_posteriors_of_a_frame_sum_to_one(eng, C, D):
+    """Size-independent property: sum_c stat0[s, c] = frames of session s and sum_c N_c = T, to float32 rounding of one
+    log-sum-exp -- not to the accumulation error of a logit (1e-4 at 156 columns).  On the two-sweep path this holds
+    because sweep 2 accumulates the logits bit-for-bit as sweep 1 did; it missed by 4e-5 when sweep 2 started its
+    accumulator at kc - lse."""
+    rng = np.random.default_rng(C * 1000 + D)
+    lens = rng.integers(1, 4, 30) * 32 + rng.integers(0, 2, 30) * 7
+    off = np.concatenate([[0], np.cumsum(lens)])
+    gmm = orc.random_gmm(C, D, seed=C + D)
+    frames = orc.synth_frames(int(off[-1]), dim=D, seed=12)
+    X = eng.upload_frames(frames)
+    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    s0, _ = eng.bw_stats(X, off, packed)
+    s0 = eng.to_host(s0)
+    defect = np.abs(s0.sum(1) - lens) / lens
+    assert defect.max() < 1e-5, defect.max()
+    N = unpack(eng.to_host(eng.estep(X, packed)), C, D)[0]
+    assert abs(N.sum() - off[-1]) / off[-1] < 2e-6
+
+
 @pytest.mark.parametrize("C,D", [(512, 60), (2048, 20), (128, 60), (512, 132), (64, 132)])
 def test_bw_stats_few_long_sessions_are_split(eng, C, D):
     """Few long sessions on the team kernel: the host cuts them into 32-frame-aligned pieces (engine._bw_split_plan) and
