@@ -4,7 +4,7 @@
 is about -300 and its float32 accumulation alone is worth 1e-4 of a posterior; "cmvn": unit-variance frames, means
 0.5 N(0,1), variances in 0.5..1.5 (what mean / variance normalised features and a trained model look like).
 Every case draws (C, D), a ragged set of sessions (empty ones, single frames, lengths that are no multiple of the
-32-frame tile) and compares skm_gmm_estep, skm_gmm_estep_noalloc (where the shape fits it) and skm_bw_stats with
+32-frame tile) and compares skm_gmm_estep, skm_gmm_estep_noalloc (where the shape fits it), skm_gmm_loglik, skm_gmm_logprob and skm_bw_stats with
 N / F / S / llk computed in float64 from the same float32 frames.  Bar: 1e-4 of the largest entry (tests/ use the
 same figure against the oracle).  A diagnostic, not part of the test suite."""
 import sys, os, math
@@ -39,7 +39,7 @@ def reference(X, w, mu, invcov, off):
         if b > a:
             s0[s] = post[a:b].sum(0)
             s1[s] = (post[a:b].T @ X64[a:b]).reshape(-1)
-    return em, s0, s1
+    return em, s0, s1, lse, lp
 
 
 def rel(a, b):
@@ -79,7 +79,7 @@ for case in range(CASES):
     mu = rng.standard_normal((C, D)) * MS
     invcov = 1.0 / (V0 + rng.random((C, D)) * V1)
     packed = eng.pack(w, mu, invcov)
-    em_ref, s0_ref, s1_ref = reference(X, w, mu, invcov, off)
+    em_ref, s0_ref, s1_ref, lse_ref, lp_ref = reference(X, w, mu, invcov, off)
     try:
         em = eng.estep(X, packed)
     except Exception as e:
@@ -95,6 +95,9 @@ for case in range(CASES):
         errs["noalloc"] = rel(out, em)       # same kernels: equal up to the order of the slab sums
     except Exception:
         pass                                    # shape beyond the built-in scratch: rejected, as documented
+    errs["loglik"] = rel(eng.loglik(X, packed).double(), lse_ref)
+    lpd, llk2 = eng.logprob(X, packed, with_loglik=True)
+    errs["logprob"] = max(rel(lpd, lp_ref), rel(llk2.double(), lse_ref))
     s0, s1 = eng.bw_stats(X, off, packed)
     errs["stat0"] = rel(s0, s0_ref); errs["stat1"] = rel(s1, s1_ref)
     s0b, s1b = eng.bw_stats(X, off, packed)                      # again into fresh tensors: no state between calls
