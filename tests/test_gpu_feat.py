@@ -236,3 +236,40 @@ def test_sliding_normalisation_without_any_labelled_frame(sk):
     x = np.random.RandomState(1).randn(400, 3)
     f, l = fs.post_processing(x, np.zeros(400, dtype=bool))
     assert f.shape == (0, 3) and l.shape == (0,)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_configurations_vs_oracle(sk, seed):
+    """Random option sets, column counts and ragged batches (sessions of 3 ... 2500 frames, some without speech, some
+    all speech) through load_batch: every session equals the oracle run on it alone."""
+    rs = np.random.RandomState(1000 + seed)
+    norm = [None, "cms", "cmvn", "cmvn_sliding", "cms_sliding"][rs.randint(5)]
+    delta = bool(rs.randint(2))
+    kw = dict(mask=None, rasta=bool(rs.randint(2)), delta=delta, double_delta=delta and bool(rs.randint(2)),
+              feat_norm=norm, keep_all_features=bool(rs.randint(2)))
+    D0 = int(rs.choice([1, 2, 5, 13, 20, 33, 44, 70]))
+    in_dtype = [np.float32, np.float64][rs.randint(2)]
+    fs = server(sk, kw)
+    names, want, want_lab = [], [], []
+    for k in range(int(rs.randint(3, 13))):
+        kind = rs.randint(3)
+        T = int(rs.randint(3, 11) if kind == 0 else rs.randint(30, 400) if kind == 1 else rs.randint(500, 2500))
+        x = (2.0 * rs.randn(T, D0) + 4.0 * rs.randn(1, D0) + np.cumsum(0.2 * rs.randn(T, D0), axis=0)).astype(in_dtype)
+        p = rs.rand()
+        lab = np.ones(T, dtype=bool) if p < 0.15 else np.zeros(T, dtype=bool) if p < 0.25 else rs.rand(T) > rs.uniform(0.1, 0.8)
+        fs.add("s%d" % k, x, lab)
+        names.append("s%d" % k)
+        with np.errstate(all="ignore"):
+            f, l = orc.post_processing(x.astype(np.float64), lab.copy(), rasta=kw["rasta"], delta=kw["delta"],
+                                       double_delta=kw["double_delta"], feat_norm=norm,
+                                       keep_all_features=kw["keep_all_features"])
+        want.append(f)
+        want_lab.append(l)
+    X, off, labels = fs.load_batch(names)
+    X, labels = X.cpu().numpy(), labels.cpu().numpy().astype(bool)
+    assert off[-1] == X.shape[0] == sum(w.shape[0] for w in want), kw
+    for k in range(len(names)):
+        assert off[k + 1] - off[k] == want[k].shape[0], (k, kw)
+        assert np.array_equal(labels[off[k]:off[k + 1]], want_lab[k]), (k, kw)
+        if want[k].shape[0]:
+            check(X[off[k]:off[k + 1]], want[k].astype(np.float32), 2e-6)
