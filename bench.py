@@ -241,13 +241,19 @@ def main():
         import shutil
         atexit.register(lambda: shutil.copyfile("/proc/self/maps", os.environ["SKM_DUMP_MAPS"]))
 
+    t_start = time.perf_counter()
     import torch
     import torch.distributed as td
+    rehearse = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        td.init_process_group("nccl", rank=rank, world_size=world)
+        # SKM_BENCH_REHEARSE=1: N ranks on ONE GPU with gloo collectives -- a rehearsal of the world > 1 branches of
+        # this file and of the drop-in classes on a one-GPU box (RCCL refuses two ranks on one device).  Its numbers
+        # are not a measurement: the ranks share the card and the collectives go through host memory.
+        rehearse = os.environ.get("SKM_BENCH_REHEARSE") == "1"
+        torch.cuda.set_device(0 if rehearse else local_rank)
+        td.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -263,6 +269,12 @@ def main():
     X = X_all[:T]
     ubm = random_ubm(sk, C, D)
 
+    verbose = os.environ.get("SKM_BENCH_VERBOSE") == "1"
+
+    def note(what):
+        if verbose:
+            print("[bench rank %d] %s  t=%.1fs" % (rank, what, time.perf_counter() - t_start), file=sys.stderr, flush=True)
+
     def sync():
         if world > 1:
             td.barrier()
@@ -277,13 +289,15 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             dt = float(tt.item())
         return dt, r
 
+    note("headline warm-up")
     if args.warmup > 0:
         em_iterations(ubm, X, args.warmup)
+    note("headline timed")
     dt, llk = timed(lambda: em_iterations(ubm, X, args.steps), 1)
     ms_per_step = 1e3 * dt / args.steps
     value = world * T * args.steps / dt
@@ -298,6 +312,9 @@ def main():
                    "components": C, "dim": D, "frames_per_gpu": T, "parallelism": "dp%d" % world,
                    "final_mean_llk": float(llk)},
     }
+
+    if rehearse:
+        result["config"]["rehearsal"] = "%d ranks share ONE GPU, gloo collectives: not a measurement" % world
 
     # ---- per-kernel timing with HIP events on the launch stream (separate, un-timed pass).  Every rank runs
     # it (the iteration contains the all-reduce); rank 0 reports its own kernels.
@@ -356,6 +373,7 @@ def main():
         return hi - lo
 
     if "em_split" in legs:
+        note("leg em_split")
         # ---- BASELINE configs[1] whole: Mixture.EM_split to C components on the rank's frames, the reference's
         # default schedule (37 EM iterations over 9 binary splits at C = 512); frames sharded, statistics all-reduced
         fs_all = sk.FeaturesServer(features={"all": X}, is_sharded=True)
@@ -381,6 +399,7 @@ def main():
         del fs_all, ubm_s
 
     if "bw" in legs:
+        note("leg bw")
         # ---- Baum-Welch N/F accumulation, BASELINE configs[3]: C=2048, 50 000 sessions x 2 000 frames in the whole
         # job, the sessions split over the ranks.  No data-path collective: every session row has one owner.
         Cb, L = 2048, 2000
@@ -443,6 +462,7 @@ def main():
             td.barrier()
 
     if "em2048" in legs:
+        note("leg em2048")
         # ---- EM iteration at the target size (BASELINE configs[2] per-GPU shape, fewer frames): C=2048
         Ce, Te = 2048, args.em2048_frames
         ubm_e = random_ubm(sk, Ce, D, seed=11)
@@ -466,6 +486,7 @@ def main():
         del ubm_e, Xe
 
     if "cfg1" in legs:
+        note("leg cfg1")
         # ---- the reference's own configuration (BASELINE configs[0]: conf.yaml UBM, 64 diagonal components on 132-dim
         # rows = 44 coefficients + deltas + double deltas): one EM iteration and the Baum-Welch pass, both on the
         # wide-row single-sweep kernels (one component tile per 512-register wave)
@@ -498,6 +519,7 @@ def main():
         torch.cuda.empty_cache()
 
     if "scoring" in legs:
+        note("leg scoring")
         # ---- GMM-UBM LLR scoring (next row after the statistics path, gmm_scoring.py:56-119): every enrolled model
         # against every test segment = one log-likelihood pass per model over all test frames + segment means.
         # Test segments are sharded over ranks, no collective.
@@ -574,6 +596,7 @@ def main():
         del iv_e, iv_t, ss
 
     if "feat" in legs:
+        note("leg feat")
         # ---- Feature post-processing in front of the path (FeaturesServer.post_processing, features_server.py:202-246;
         # the experiment's configuration model_interface.py:45-52: RASTA + delta + double delta + cmvn), raw 20-dim
         # cepstra + VAD labels in HBM -> normalised 60-dim float32 frames of the labelled rows.  HBM-bound streaming;
@@ -632,6 +655,7 @@ def main():
         del raw, vad, fo
 
     if "tv" in legs:
+        note("leg tv")
         # ---- TV training iteration + i-vector extraction, BASELINE configs[4]: R=400, C=2048, 50 000 sessions in the
         # whole job, split over the ranks; training reduce-scatters the accumulators over components, solves its C/N
         # components and all-gathers the new rows (factor_analyser._tv_iteration).

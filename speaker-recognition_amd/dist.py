@@ -57,11 +57,22 @@ def _nbytes(t):
     return int(t.numel()) * int(t.element_size())
 
 
+def _gloo_on_device(t):
+    """A device tensor under the gloo backend: only bench.py's one-GPU rehearsal (SKM_BENCH_REHEARSE=1) gets here.
+    gloo's own handling of device tensors hung on this ROCm build, so the collective runs on a host copy."""
+    return t.is_cuda and _td().get_backend() == "gloo"
+
+
 def allreduce_sum_(t):
     """In-place sum over ranks of a torch tensor (device tensor -> RCCL, CPU tensor -> gloo)."""
     if is_dist():
         PAYLOAD["all_reduce"] += _nbytes(t)
-        _td().all_reduce(t)
+        if _gloo_on_device(t):
+            h = t.cpu()
+            _td().all_reduce(h)
+            t.copy_(h)
+        else:
+            _td().all_reduce(t)
     return t
 
 
@@ -87,6 +98,10 @@ def allgather_rows(t, counts):
     out = torch.empty((w * m,) + tail, dtype=t.dtype, device=t.device)
     if td.get_backend() == "nccl":
         td.all_gather_into_tensor(out, send)
+    elif _gloo_on_device(t):
+        h = torch.empty((w * m,) + tail, dtype=t.dtype)
+        td.all_gather(list(h.view((w, m) + tail).unbind(0)), send.cpu())
+        out.copy_(h)
     else:
         td.all_gather(list(out.view((w, m) + tail).unbind(0)), send)
     if all(c == m for c in counts):
@@ -111,6 +126,10 @@ def reduce_scatter_rows(t):
         out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         td.reduce_scatter_tensor(out, t)
         return out
+    if _gloo_on_device(t):
+        h = t.cpu()
+        td.all_reduce(h)
+        return h[r * n:(r + 1) * n].to(t.device)
     td.all_reduce(t)
     return t[r * n:(r + 1) * n].clone()
 
