@@ -320,6 +320,39 @@ def test_statserver_accumulate_stat_dropin(sk):
         ss.accumulate_stat(ubm=ubm, feature_server=bad, seg_indices=range(2))
 
 
+def test_statserver_accumulate_stat_pipelined_batches(sk, eng):
+    """The drop-in call on a job of several device batches (2.2 M frames: three batches of about 2^20 frames, uploads,
+    kernels and the copy off the device overlapped on two streams and a worker thread): every row lands in its place
+    and equals what one call of the kernel entry point over all frames returns; a sample of sessions against the
+    oracle."""
+    C, D, S = 64, 20, 1300
+    rs = np.random.RandomState(77)
+    lens = rs.randint(500, 3000, size=S)
+    lens[[3, 700]] = [1, 2]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    frames = orc.synth_frames(int(off[-1]), dim=D, clusters=16, seed=78)
+    assert frames.shape[0] > 2 * (1 << 20)
+    gmm = orc.random_gmm(C, D, seed=79)
+    names = ["s%04d" % i for i in range(S)]
+    fs = sk.FeaturesServer(features={n: frames[off[i]:off[i + 1]] for i, n in enumerate(names)})
+    ubm = sk.Mixture()
+    ubm.w, ubm.mu, ubm.invcov = gmm.w.copy(), gmm.mu.copy(), gmm.invcov.copy()
+    ubm.cov_var_ctl = 1.0 / ubm.invcov
+    ubm._compute_all()
+    ss = sk.StatServer(sk.IdMap().set(["spk%d" % (i % 50) for i in range(S)], names), ubm=ubm)
+    ss.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(S), num_thread=1)
+    assert ss.stat0.shape == (S, C) and ss.stat1.shape == (S, C * D)
+    assert np.abs(ss.stat0.sum(1) - lens).max() / lens.max() < 1e-5
+    t0, t1 = eng.bw_stats(eng.upload_frames(frames), off, eng.pack(gmm.w, gmm.mu, gmm.invcov))
+    t0, t1 = eng.to_host(t0), eng.to_host(t1)
+    for i in range(S):      # row by row: a row that landed in the wrong place or was never written shows here
+        assert np.abs(ss.stat0[i] - t0[i]).max() <= 5e-5 * max(np.abs(t0[i]).max(), 1e-30), i
+        assert np.abs(ss.stat1[i] - t1[i]).max() <= 5e-5 * max(np.abs(t1[i]).max(), 1e-30), i
+    pick = [0, 3, 411, 700, 1299]
+    r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in pick])
+    assert rel(ss.stat0[pick], r0) < TOL and rel(ss.stat1[pick], r1) < TOL
+
+
 def test_em_split_dropin_vs_reference_golden(sk):
     g = golden("em_split.npz")
     chunks = {"f%d" % i: g["chunk%d" % i] for i in range(4)}
