@@ -1,5 +1,5 @@
 """Random shapes through the GMM entry points against a float64 torch restatement on the device:
-    python tools/fuzz_gmm.py [cases] [seed] [harsh|cmvn]
+    python tools/fuzz_gmm.py [cases] [seed] [harsh|cmvn] [big]
 "harsh" (default): frames 0.3 + 1.5 N(0,1), means 1.2 N(0,1), variances in 0.4..1.9, so a logit of a 159-column row
 is about -300 and its float32 accumulation alone is worth 1e-4 of a posterior; "cmvn": unit-variance frames, means
 0.5 N(0,1), variances in 0.5..1.5 (what mean / variance normalised features and a trained model look like).
@@ -15,6 +15,7 @@ import sidekit_amd as sk
 CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 REGIME = sys.argv[3] if len(sys.argv) > 3 else "harsh"
+BIG = len(sys.argv) > 4 and sys.argv[4] == "big"      # 0.1 ... 1.5 M frames in up to 3000 sessions (many workgroups, long streams)
 XS, XM, MS, V0, V1 = (1.5, 0.3, 1.2, 0.4, 1.5) if REGIME == "harsh" else (1.0, 0.0, 0.5, 0.5, 1.0)
 rng = np.random.default_rng(SEED)
 eng = sk.default_engine()
@@ -50,6 +51,15 @@ def rel(a, b):
 def draw_sessions():
     kind = rng.integers(0, 5)
     ns = int(rng.integers(1, 40))
+    if BIG:
+        total = int(rng.integers(100_000, 1_500_000))
+        mean = [40, 300, 2000, 20000][rng.integers(0, 4)]
+        ns = max(1, min(3000, total // mean))
+        lens = np.maximum(0, rng.normal(total / ns, 0.4 * total / ns, ns)).astype(np.int64)
+        lens[rng.random(ns) < 0.05] = 0
+        if lens.sum() == 0:
+            lens[0] = 5
+        return np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     if kind == 0:
         lens = rng.integers(0, 70, ns)
     elif kind == 1:
