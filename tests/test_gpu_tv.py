@@ -315,3 +315,39 @@ def test_full_size_invariants_cfg5_shape(eng):
     # sum_c N_sc = n_tot for every session (float32 rounding of the posteriors aside)
     Au = up(A)
     assert rel(Au[:C].sum(0), n_tot * Au[C]) < 1e-5
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_tv_shapes_vs_oracle(eng, seed):
+    """Random (C, D, R, sessions, batch) through whitening, the E-step accumulators, both i-vector routes and the
+    M-step against the oracle (the part of tools/fuzz_tv.py that fits a test).  Statistics as sessions of 100 ... 3000
+    frames would give them: N_c >= 0 summing to the frame count, F_c = N_c (mu_c + offset) + noise."""
+    rs = np.random.RandomState(4000 + seed)
+    while True:
+        C, D, R = int(rs.choice([1, 2, 5, 16, 24, 33, 40])), int(rs.choice([1, 3, 8, 12, 13, 20])), \
+            int(rs.choice([1, 2, 5, 6, 31, 32, 33, 50, 64, 100, 128]))
+        if R <= C * D:
+            break
+    S, batch = int(rs.choice([1, 2, 7, 31, 33, 64])), int(rs.choice([1, 5, 32, 100]))
+    gmm = orc.random_gmm(C, D, seed=seed)
+    frames = rs.randint(100, 3000, size=S)
+    post = rs.dirichlet(np.full(C, 0.3), size=S) * frames[:, None]
+    s0 = post.astype(np.float32)
+    nrep = np.repeat(post, D, axis=1)
+    s1 = (nrep * (gmm.mu.flatten()[None, :] + 0.3 * rs.randn(S, C * D))
+          + np.sqrt(nrep / gmm.invcov.flatten()[None, :]) * rs.randn(S, C * D)).astype(np.float32)
+    Fm = 0.1 * rs.randn(C * D, R)
+    what = "seed %d: C=%d D=%d R=%d S=%d batch=%d" % (seed, C, D, R, S, batch)
+    A, Cc, e_h, sig, A_dev, C_dev = _accumulators(eng, gmm, s0, s1, Fm, batch)
+    rA, rC, rR = orc.tv_accumulate(s0, s1, gmm, Fm, batch_size=300)
+    rR = rR * S
+    assert rel(_upper_packed(A[:C]), rA) < 1e-4 and rel(Cc, rC) < 1e-4 and rel(_upper_packed(A[C]), rR) < 1e-4, what
+    iv, iv_sigma = orc.extract_ivectors(s0, s1, gmm, Fm)
+    assert rel(e_h, iv) < 1e-4 and rel(sig, iv_sigma) < 1e-4 and min_cosine(e_h, iv) > 0.9999, what
+    ft, naug = eng.tv_whiten(dev(eng, s0), dev(eng, s1), gmm.mu.flatten(), gmm.invcov.flatten())
+    T32, G = eng.tv_prepare(dev(eng, Fm), C, D)
+    e_s, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=False)
+    assert rel(eng.to_host(e_s), iv) < 1e-4, what
+    if S >= 2 * R:      # fewer sessions than factors: A_c nearly singular, the solve magnifies the 1e-6 of its inputs
+        Fn = eng.to_host(eng.tv_mstep(A_dev, C_dev, C, D, R))
+        assert rel(Fn, orc.tv_mstep(rA, rC, rR / S, D, min_div=False)) < 1e-4, what
