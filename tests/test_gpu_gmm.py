@@ -597,6 +597,40 @@ def test_gmm_scoring_vs_oracle_c512(sk):
     assert (sc.scoremat[~sc.scoremask] == 0).all()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_gmm_scoring_random_shapes_vs_oracle(sk, seed):
+    """Random (C, D), numbers of models and segments, segment lengths from 1 frame to two thousand, random trial masks
+    (rows / columns without any trial included) against the oracle's log-likelihood ratios."""
+    rs = np.random.RandomState(7000 + seed)
+    C = int(rs.choice([1, 2, 33, 64, 100, 256, 512, 1000, 2048]))
+    D = int(rs.choice([5, 13, 20, 39, 60, 64, 100, 132]))
+    M, K = int(rs.randint(1, 9)), int(rs.randint(1, 12))
+    gmm = orc.random_gmm(C, D, seed=seed)
+    ubm = _ubm_from(sk, gmm.w, gmm.mu, gmm.invcov)
+    models = np.array(["m%02d" % i for i in range(M)])
+    means = gmm.mu.reshape(1, -1) + 0.05 * rs.randn(M, C * D)
+    enroll = sk.StatServer()
+    enroll.modelset = models.copy()
+    enroll.segset = models.copy()
+    enroll.start = np.empty(M, "|O")
+    enroll.stop = np.empty(M, "|O")
+    enroll.stat0 = np.ones((M, 1))
+    enroll.stat1 = means
+    segs = np.array(["t%02d" % i for i in range(K)])
+    lens = [int(rs.choice([1, 2, 31, 32, 33, int(rs.randint(34, 2000))])) for _ in range(K)]
+    feats = {s: orc.synth_frames(L, dim=D, clusters=8, seed=300 + 20 * seed + i) for i, (s, L) in enumerate(zip(segs, lens))}
+    ndx = sk.Ndx()
+    ndx.modelset, ndx.segset = models, segs
+    ndx.trialmask = rs.rand(M, K) < 0.6
+    sc = sk.gmm_scoring(ubm, enroll, ndx, sk.FeaturesServer(features=feats))
+    assert list(sc.modelset) == list(models) and list(sc.segset) == list(segs)
+    ref = orc.gmm_scoring(gmm, list(models), means, sc.modelset, sc.segset, sc.scoremask,
+                          {s: np.asarray(f, dtype=np.float64) for s, f in feats.items()})
+    what = "seed %d: C=%d D=%d models=%d segments=%d lens=%s" % (seed, C, D, M, K, lens)
+    assert np.abs(sc.scoremat - ref).max() < 2e-4, (what, np.abs(sc.scoremat - ref).max())
+    assert (sc.scoremat[~sc.scoremask] == 0).all(), what
+
+
 @pytest.mark.parametrize("C,D", [(8, 6), (40, 13), (512, 60), (96, 20)])
 def test_device_mstep_and_repack_equal_host_path(sk, eng, C, D):
     """skm_gmm_mstep_pack (M-step + variance control + re-pack in HBM) against the host float64 M-step of the
