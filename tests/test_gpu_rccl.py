@@ -125,7 +125,7 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(os.path.dirname(os.path.abspath(__file__)), "rehearse_worker.py"), str(out)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     two = np.load(out)
     plain = _run_all(sk)
