@@ -121,6 +121,11 @@ int skm_gmm_loglik(void *ctx, const float *X_dev, long T, int C, int D, const vo
 int skm_gmm_logprob(void *ctx, const float *X_dev, long T, int C, int D, const void *packed_dev,
                     double *lp_dev, float *loglik_dev, void *ws_dev, size_t ws_bytes, void *stream);
 
+/* sum_log_probabilities on a matrix the caller already holds (sidekit/mixture.py:52-64, sidekit/statserver.py:83-95):
+ * lp_dev[T*C] float64 -> pp_dev[T*C] = exp(lp - log_lk) (optional, NULL) and loglk_dev[T] = row log-sum-exp (optional);
+ * a row whose maximum is not finite gets log_lk = that maximum, NaN propagates as numpy.max does.  float64. */
+int skm_row_logsumexp(void *ctx, const double *lp_dev, long T, int C, double *pp_dev, double *loglk_dev, void *stream);
+
 /* Baum-Welch statistics per session.  Session s owns frames [seg_off[s], seg_off[s+1]) of X
  * (seg_off: S+1 int64 on the device, non-decreasing, seg_off[S] <= T).
  *   stat0_dev[S*C]      float64   zero order  (sum_t gamma)
@@ -137,6 +142,24 @@ int skm_bw_stats(void *ctx, const float *X_dev, long T, const int64_t *seg_off_d
  * pieces (speaker-recognition_amd/engine.py: _bw_split_plan).  No counterpart in the reference: its loop over
  * sessions (sidekit/statserver.py:647-667) is serial. */
 int skm_bw_team_count(void *ctx, int C, int D);
+
+/* Frame centring for un-normalised features (raw cepstra with c0 / log-energy offsets, no cmvn).  The kernels above
+ * accumulate the logits in float32, whose absolute error grows with sum_d mu_d^2 / sigma_d^2; the reference does the
+ * same two products in float64 (sidekit/mixture.py:482-486).  The whole path is translation invariant, so a caller
+ * whose data sit far from the origin runs it on x' = x - m with a model packed from mu' = mu - m (skm_gmm_pack on the
+ * shifted means) and maps the statistics back exactly:
+ *   skm_frames_center      out_dev[t*D + d] = X_dev[t*D + d] - (float)shift_dev[d]      (in place when out_dev == X_dev)
+ *   skm_gmm_stats_unshift  [N | F' | S' | llk] of skm_gmm_estep, in place:  F = F' + N m,  S = S' + 2 m F' + N m^2
+ *                          (mixture.py:557-562 on the un-shifted frames); N and llk do not change
+ *   skm_bw_unshift         stat1[s][c*D + d] += stat0[s][c] * m[d]                      (statserver.py:664-666)
+ * with m[d] = (double)(float)shift_dev[d] in all three (shift_dev: D doubles on the device), so that the frames, the
+ * model and the correction use the same number.  speaker-recognition_amd/mixture.py decides when to centre (mean of the
+ * model or of the data further than half a standard deviation from the origin in some dimension). */
+int skm_frames_center(void *ctx, const float *X_dev, long T, int D, const double *shift_dev, float *out_dev,
+                      void *stream);
+int skm_gmm_stats_unshift(void *ctx, double *stats_dev, int C, int D, const double *shift_dev, void *stream);
+int skm_bw_unshift(void *ctx, const double *stat0_dev, double *stat1_dev, long S, int C, int D,
+                   const double *shift_dev, void *stream);
 
 /* Mean of v over each segment [seg_off[s], seg_off[s+1]) (seg_off: S+1 int64, dev), float64 sums:
  * out_dev[s] = mean(v[seg_off[s] : seg_off[s+1]]); an empty segment gives NaN (numpy's mean of nothing).

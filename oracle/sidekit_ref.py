@@ -414,6 +414,38 @@ def random_gmm(C, D, seed=7):
     return GMM(w, mu, 1.0 / var)
 
 
+def raw_scales(dim, scale_seed=99):
+    """Per-dimension offset (up to +-30, the first column -- c0 / log-energy -- the farthest out) and spread of
+    the cluster means of un-normalised, raw-MFCC-like features."""
+    rs = np.random.RandomState(scale_seed)
+    off = rs.uniform(-30.0, 30.0, size=dim)
+    off[0] = -30.0
+    spread = rs.uniform(1.0, 6.0, size=dim)
+    return off, spread
+
+
+def synth_raw_frames(n, dim=60, clusters=16, seed=1234, dtype=np.float32, scale_seed=99):
+    """Raw-MFCC-like frames, NO cmvn: per-dimension offsets up to +-30, cluster variances log-uniform in
+    [1, 100] (the regime in which float32 logits of un-centred frames lose the 1e-4 bar)."""
+    off, spread = raw_scales(dim, scale_seed)
+    rs = np.random.RandomState(seed)
+    means = off[None, :] + spread[None, :] * rs.randn(clusters, dim)
+    std = np.sqrt(np.exp(rs.uniform(0.0, np.log(100.0), size=(clusters, dim))))
+    lab = rs.randint(0, clusters, size=n)
+    x = means[lab] + std[lab] * rs.randn(n, dim)
+    return np.ascontiguousarray(x.astype(dtype))
+
+
+def raw_gmm(C, D, seed=7, scale_seed=99):
+    """A UBM for synth_raw_frames data: means around the same offsets, variances log-uniform in [1, 100]."""
+    off, spread = raw_scales(D, scale_seed)
+    rs = np.random.RandomState(seed)
+    w = rs.dirichlet(np.full(C, 5.0))
+    mu = off[None, :] + spread[None, :] * rs.randn(C, D)
+    var = np.exp(rs.uniform(0.0, np.log(100.0), size=(C, D)))
+    return GMM(w, mu, 1.0 / var)
+
+
 # ----------------------------------------------------------------------------------------
 # next row (SURVEY 8f rank 1): MAP mean adaptation and GMM-UBM log-likelihood-ratio scoring
 # ----------------------------------------------------------------------------------------

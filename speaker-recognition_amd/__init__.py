@@ -4,7 +4,7 @@ a SIDEKIT 1.3.2 fork).  Import through the repo-root shim:  `import sidekit_amd 
 from .engine import HipEngine, SkmError, default_engine, set_default_engine, load_library, LIB_PATH  # noqa: F401
 from .idmap import IdMap, Ndx, Scores, Key  # noqa: F401
 from .features_server import FeaturesServer  # noqa: F401
-from .mixture import Mixture  # noqa: F401
+from .mixture import Mixture, sum_log_probabilities  # noqa: F401
 from .statserver import StatServer  # noqa: F401
 from .factor_analyser import FactorAnalyser  # noqa: F401
 from .gmm_scoring import gmm_scoring, gmm_scoring_singleThread  # noqa: F401

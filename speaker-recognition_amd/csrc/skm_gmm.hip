@@ -1366,6 +1366,161 @@ extern "C" int skm_moments(void *ctx_, const float *X, long T, int D, double *ou
 }
 
 // ------------------------------------------------------------------------------------------------
+// Frame centring for un-normalised features.  The logits are accumulated in float32, so their absolute error grows
+// with sum_d mu_d^2 / sigma_d^2; raw cepstra (c0 / log-energy offsets of tens, no cmvn) put that in the thousands and
+// the posteriors lose the 1e-4 bar.  Everything on this path is translation invariant: with x' = x - m and
+// mu' = mu - m the posteriors, N and the log-likelihood are unchanged, and
+//   F = F' + N m,   S = S' + 2 m F' + N m^2   (per component),   stat1 = stat1' + stat0 (x) m   (per session).
+// The shift every kernel applies is the float32 rounding of shift[d] (so that x - m is the same number on both
+// sides of the identity); the host packs the model with the same rounded value.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_frames_center(const float *__restrict__ X, long n, int D,
+                                                       const double *__restrict__ shift, float *__restrict__ out)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = X[i] - (float)shift[(int)(i % D)];
+}
+
+// rows of D % 4 == 0 floats: 16 bytes per lane, the four columns of a vector stay inside one row
+__global__ __launch_bounds__(256) void k_frames_center4(const f32x4 *__restrict__ X, long n4, int D4,
+                                                        const double *__restrict__ shift, f32x4 *__restrict__ out)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int d = 4 * (int)(i % D4);
+        f32x4 v = X[i];
+        v.x -= (float)shift[d];
+        v.y -= (float)shift[d + 1];
+        v.z -= (float)shift[d + 2];
+        v.w -= (float)shift[d + 3];
+        out[i] = v;
+    }
+}
+
+extern "C" int skm_frames_center(void *ctx_, const float *X, long T, int D, const double *shift_dev, float *out,
+                                 void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && shift_dev && D > 0 && T >= 0 && (T == 0 || (X && out)), "skm_frames_center: bad argument");
+    if (T == 0) return SKM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    SkmProfScope ps(ctx, "k_frames_center", st);
+    const long n = T * D;
+    if (D % 4 == 0 && (((uintptr_t)X | (uintptr_t)out) & 15) == 0) {
+        const long n4 = n / 4;
+        long blocks = (n4 + 255) / 256;
+        if (blocks > (long)ctx->cu_count * 16) blocks = (long)ctx->cu_count * 16;
+        hipLaunchKernelGGL(k_frames_center4, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(X),
+                           n4, D / 4, shift_dev, reinterpret_cast<f32x4 *>(out));
+    } else {
+        long blocks = (n + 255) / 256;
+        if (blocks > (long)ctx->cu_count * 16) blocks = (long)ctx->cu_count * 16;
+        hipLaunchKernelGGL(k_frames_center, dim3((unsigned)blocks), dim3(256), 0, st, X, n, D, shift_dev, out);
+    }
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
+__global__ __launch_bounds__(256) void k_stats_unshift(double *__restrict__ stats, int C, int D,
+                                                       const double *__restrict__ shift)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)C * D) return;
+    const int c = (int)(e / D), d = (int)(e - (long)c * D);
+    const double m = (double)(float)shift[d];
+    const double n = stats[c], f = stats[(size_t)C + e], s = stats[(size_t)C + (size_t)C * D + e];
+    stats[(size_t)C + e] = f + n * m;
+    stats[(size_t)C + (size_t)C * D + e] = s + m * (2.0 * f + n * m);
+}
+
+extern "C" int skm_gmm_stats_unshift(void *ctx_, double *stats_dev, int C, int D, const double *shift_dev, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && stats_dev && shift_dev && C > 0 && D > 0, "skm_gmm_stats_unshift: bad argument");
+    SkmProfScope ps(ctx, "k_stats_unshift", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_stats_unshift, dim3((unsigned)(((long)C * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       stats_dev, C, D, shift_dev);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
+__global__ __launch_bounds__(256) void k_bw_unshift(const double *__restrict__ stat0, double *__restrict__ stat1, long S,
+                                                    int C, int D, const double *__restrict__ shift)
+{
+    const long CD = (long)C * D, n = S * CD;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long s = i / CD;
+        const int r = (int)(i - s * CD), c = r / D, d = r - c * D;
+        stat1[i] += stat0[s * C + c] * (double)(float)shift[d];
+    }
+}
+
+extern "C" int skm_bw_unshift(void *ctx_, const double *stat0_dev, double *stat1_dev, long S, int C, int D,
+                              const double *shift_dev, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && shift_dev && C > 0 && D > 0 && S >= 0 && (S == 0 || (stat0_dev && stat1_dev)),
+                "skm_bw_unshift: bad argument");
+    if (S == 0) return SKM_OK;
+    SkmProfScope ps(ctx, "k_bw_unshift", (hipStream_t)stream);
+    long blocks = (S * (long)C * D + 255) / 256;
+    if (blocks > (long)ctx->cu_count * 16) blocks = (long)ctx->cu_count * 16;
+    hipLaunchKernelGGL(k_bw_unshift, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, stat0_dev, stat1_dev, S, C,
+                       D, shift_dev);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sum_log_probabilities on a T x C float64 matrix the caller already holds (sidekit/mixture.py:52-64,
+// sidekit/statserver.py:83-95): row maximum, log_lk = max + log sum exp(lp - max) (the maximum itself where it is not
+// finite), pp = exp(lp - log_lk).  One wave per row, float64, fixed order.  The statistics kernels never need this --
+// they fuse it -- it serves callers that import the helper by name.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_lse(const double *__restrict__ lp, long T, int C, double *__restrict__ pp,
+                                                 double *__restrict__ log_lk)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const double *src = lp + row * C;
+    double m = -__builtin_inf();
+    bool has_nan = false;
+    for (int c = lane; c < C; c += 64) {
+        const double v = src[c];
+        has_nan |= (v != v);
+        m = fmax(m, v);
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) {
+        m = fmax(m, __shfl_xor(m, k));
+        has_nan |= (bool)__shfl_xor((int)has_nan, k);
+    }
+    if (has_nan) m = __builtin_nan("");               // numpy.max propagates NaN
+    double s = 0.0;
+    for (int c = lane; c < C; c += 64) s += exp(src[c] - m);
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
+    double l = m + log(s);
+    if (!isfinite(m)) l = m;
+    if (lane == 0 && log_lk) log_lk[row] = l;
+    if (pp)
+        for (int c = lane; c < C; c += 64) pp[row * C + c] = exp(src[c] - l);
+}
+
+extern "C" int skm_row_logsumexp(void *ctx_, const double *lp_dev, long T, int C, double *pp_dev, double *loglk_dev,
+                                 void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && T >= 0 && C > 0 && (T == 0 || lp_dev), "skm_row_logsumexp: bad argument");
+    if (T == 0) return SKM_OK;
+    SkmProfScope ps(ctx, "k_row_lse", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_row_lse, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, lp_dev, T, C, pp_dev,
+                       loglk_dev);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // per-segment mean of a float32 vector in float64 (gmm_scoring: mean frame log-likelihood of a test
 // segment, sidekit/gmm_scoring.py:107,116).  One workgroup per segment, fixed summation order.
 // ------------------------------------------------------------------------------------------------

@@ -45,8 +45,12 @@ SIGNATURES = {
                                 _c_void_p, _c_size_t, _c_void_p]),
     "skm_gmm_logprob": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
                                  _c_void_p, _c_size_t, _c_void_p]),
+    "skm_row_logsumexp": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "skm_bw_stats": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
                               _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "skm_frames_center": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "skm_gmm_stats_unshift": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "skm_bw_unshift": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p]),
     "skm_segment_mean": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "skm_row_normalize": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
     "skm_class_sums": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
@@ -206,19 +210,56 @@ class HipEngine(object):
         return t.contiguous()
 
     # ------------------------------------------------------------------ GMM
-    def pack(self, w, mu, invcov):
+    def frame_shift(self, m):
+        """A FrameShift for the per-dimension offset m (None passes through)."""
+        if m is None or isinstance(m, FrameShift):
+            return m
+        return FrameShift(self, m)
+
+    def center_frames(self, X, shift, inplace=False):
+        """X - shift as float32 (skm_frames_center); `inplace` overwrites X (the caller owns it)."""
+        torch = self.torch
+        assert X.dim() == 2 and X.dtype == torch.float32 and X.is_contiguous() and X.shape[1] == shift.D
+        out = X if inplace else torch.empty_like(X)
+        self._check(self.lib.skm_frames_center(self.ctx, _c_void_p(X.data_ptr()), X.shape[0], X.shape[1],
+                                               _c_void_p(shift.dev.data_ptr()), _c_void_p(out.data_ptr()),
+                                               self._stream()))
+        return out
+
+    def stats_unshift_(self, flat, C, D, shift):
+        """[N | F' | S' | llk] of centred frames -> the statistics of the frames themselves, in place."""
+        assert flat.dtype == self.torch.float64 and flat.numel() == 2 * C * D + C + 1 and flat.is_contiguous()
+        self._check(self.lib.skm_gmm_stats_unshift(self.ctx, _c_void_p(flat.data_ptr()), C, D,
+                                                   _c_void_p(shift.dev.data_ptr()), self._stream()))
+        return flat
+
+    def bw_unshift_(self, stat0, stat1, D, shift):
+        S, C = stat0.shape
+        assert stat1.shape == (S, C * D) and stat0.is_contiguous() and stat1.is_contiguous()
+        self._check(self.lib.skm_bw_unshift(self.ctx, _c_void_p(stat0.data_ptr()), _c_void_p(stat1.data_ptr()), S, C, D,
+                                            _c_void_p(shift.dev.data_ptr()), self._stream()))
+        return stat1
+
+    def pack(self, w, mu, invcov, shift=None):
+        """Device image of the model.  With `shift` (a FrameShift) the image is the model of the CENTRED frames
+        x - shift (means mu - shift): estep / bw_stats / loglik / logprob then centre the frames they are given
+        (or take them as already centred, `centered=True`) and map the statistics back."""
         torch = self.torch
         w = _as_f64(w)
         mu = _as_f64(mu)
         invcov = _as_f64(invcov)
         C, D = mu.shape
         assert w.shape == (C,) and invcov.shape == (C, D)
+        shift = self.frame_shift(shift)
+        if shift is not None:
+            assert shift.D == D
+            mu = mu - shift.host[None, :]
         nbytes = self.lib.skm_gmm_packed_bytes(C, D)
         packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._check(self.lib.skm_gmm_pack(self.ctx, w.ctypes.data_as(_dp), mu.ctypes.data_as(_dp),
                                           invcov.ctypes.data_as(_dp), C, D, _c_void_p(packed.data_ptr()),
                                           self._stream()))
-        return PackedGMM(packed, C, D)
+        return PackedGMM(packed, C, D, shift)
 
     def mstep_pack(self, stats, cov_var_ctl, gmm, ceil_cov, floor_cov, params=None, llk_mean=None):
         """M-step + re-pack on the device (skm_gmm_mstep_pack): `gmm` (a PackedGMM) is overwritten with the new
@@ -235,13 +276,29 @@ class HipEngine(object):
             _c_void_p(llk_mean.data_ptr()) if llk_mean is not None else None, self._stream()))
         return params
 
-    def estep(self, X, gmm, out=None, accumulate=False):
-        """[N | F | S | llk] float64 device tensor for the frames X (T x D float32 device tensor)."""
+    def estep(self, X, gmm, out=None, accumulate=False, centered=False, unshift=True):
+        """[N | F | S | llk] float64 device tensor for the frames X (T x D float32 device tensor).
+        A model packed with a shift: X is centred here unless `centered` says it already is, and the statistics
+        are mapped back to those of the frames themselves unless `unshift` is False (the device EM loop runs its
+        M-step in the centred coordinates)."""
         torch = self.torch
         T, D = X.shape
         assert D == gmm.D and X.dtype == torch.float32 and X.is_contiguous()
         C = gmm.C
         n = 2 * C * D + C + 1
+        if gmm.shift is not None:
+            if not centered:
+                X = self.center_frames(X, gmm.shift)
+            if unshift:
+                part = self.estep(X, _unshifted(gmm), centered=True)
+                self.stats_unshift_(part, C, D, gmm.shift)
+                if out is None or not accumulate:
+                    if out is None:
+                        return part
+                    out.copy_(part)
+                else:
+                    out += part
+                return out
         if out is None:
             out = torch.empty(n, dtype=torch.float64, device=self.device)
             accumulate = False
@@ -265,10 +322,12 @@ class HipEngine(object):
                                                    1 if accumulate else 0, self._stream()))
         return out
 
-    def loglik(self, X, gmm):
+    def loglik(self, X, gmm, centered=False):
         torch = self.torch
         T, D = X.shape
         assert D == gmm.D
+        if gmm.shift is not None and not centered:
+            X = self.center_frames(X, gmm.shift)
         out = torch.empty(T, dtype=torch.float32, device=self.device)
         need = self.lib.skm_gmm_workspace_bytes(self.ctx, T, gmm.C, D)
         ws = self.workspace(need)
@@ -277,11 +336,13 @@ class HipEngine(object):
                                             _c_void_p(ws), need, self._stream()))
         return out
 
-    def logprob(self, X, gmm, with_loglik=False):
+    def logprob(self, X, gmm, with_loglik=False, centered=False):
         """T x C float64 device matrix ln(w_c N(x_t; c)) [and the T float32 row log-sum-exp]."""
         torch = self.torch
         T, D = X.shape
         assert D == gmm.D and X.dtype == torch.float32 and X.is_contiguous()
+        if gmm.shift is not None and not centered and T > 0:
+            X = self.center_frames(X, gmm.shift)
         lp = torch.empty((T, gmm.C), dtype=torch.float64, device=self.device)
         llk = torch.empty(T, dtype=torch.float32, device=self.device) if with_loglik else None
         if T == 0:
@@ -293,6 +354,18 @@ class HipEngine(object):
                                              _c_void_p(llk.data_ptr()) if with_loglik else None,
                                              _c_void_p(ws), need, self._stream()))
         return (lp, llk) if with_loglik else lp
+
+    def row_logsumexp(self, lp, want_pp=True):
+        """(pp, log_lk) of a T x C float64 device matrix of log-probabilities (skm_row_logsumexp)."""
+        torch = self.torch
+        assert lp.dim() == 2 and lp.dtype == torch.float64 and lp.is_contiguous()
+        T, C = lp.shape
+        pp = torch.empty_like(lp) if want_pp else None
+        llk = torch.empty(T, dtype=torch.float64, device=self.device)
+        self._check(self.lib.skm_row_logsumexp(self.ctx, _c_void_p(lp.data_ptr()), T, C,
+                                               _c_void_p(pp.data_ptr()) if want_pp else None,
+                                               _c_void_p(llk.data_ptr()), self._stream()))
+        return pp, llk
 
     def _bw_split_plan(self, seg_host, C, D=60):
         """Few long sessions leave teams of the Baum-Welch kernel idle (whole sessions are dealt to the teams of
@@ -325,11 +398,19 @@ class HipEngine(object):
             return None
         return np.asarray(offs, dtype=np.int64), np.asarray(owner, dtype=np.int64)
 
-    def bw_stats(self, X, seg_off, gmm, stat0=None, stat1=None, split_long=True):
-        """Per-session N (S x C) and F (S x C*D, component-major), float64 device tensors."""
+    def bw_stats(self, X, seg_off, gmm, stat0=None, stat1=None, split_long=True, centered=False, own_frames=False):
+        """Per-session N (S x C) and F (S x C*D, component-major), float64 device tensors.  A model packed with a
+        shift: X is centred first (in place when the caller gives it up, `own_frames`) unless `centered`, and
+        stat1 is mapped back (stat1 += stat0 (x) shift)."""
         torch = self.torch
         T, D = X.shape
         assert D == gmm.D and X.dtype == torch.float32 and X.is_contiguous()
+        if gmm.shift is not None:
+            if not centered and T > 0:
+                X = self.center_frames(X, gmm.shift, inplace=own_frames)
+            stat0, stat1 = self.bw_stats(X, seg_off, _unshifted(gmm), stat0, stat1, split_long)
+            self.bw_unshift_(stat0, stat1, D, gmm.shift)
+            return stat0, stat1
         if split_long and not isinstance(seg_off, torch.Tensor):
             plan = self._bw_split_plan(np.asarray(seg_off, dtype=np.int64), gmm.C, gmm.D)
             if plan is not None:
@@ -881,12 +962,47 @@ class HipEngine(object):
 
 
 class PackedGMM(object):
-    """Device image of a diagonal GMM in MFMA fragment order (see csrc/skm_gmm.hip)."""
+    """Device image of a diagonal GMM in MFMA fragment order (see csrc/skm_gmm.hip).  `shift` (a FrameShift or
+    None): the image is the model of the frames minus that offset."""
 
-    def __init__(self, packed, C, D):
+    def __init__(self, packed, C, D, shift=None):
         self.packed = packed
         self.C = C
         self.D = D
+        self.shift = shift
+
+
+def _unshifted(gmm):
+    """The same device image seen as a plain model (of the centred frames)."""
+    return PackedGMM(gmm.packed, gmm.C, gmm.D, None)
+
+
+class FrameShift(object):
+    """Per-dimension offset subtracted from un-normalised frames (include/skm.h, skm_frames_center).  `host` is the
+    float32 rounding of the requested offset, as float64: the one number the frames, the model and the
+    back-mapping of the statistics all use."""
+
+    def __init__(self, engine, m):
+        m32 = np.asarray(m, dtype=np.float64).reshape(-1).astype(np.float32)
+        self.host = m32.astype(np.float64)
+        self.D = self.host.size
+        self.dev = engine.torch.from_numpy(self.host.copy()).to(engine.device)
+
+
+def centering_offset(mean, std):
+    """Offset to centre frames on, or None when the data already sit at the origin: some dimension's mean is more
+    than half a standard deviation away from zero.  cmvn / cms features never qualify (the unchanged float32 path);
+    raw cepstra do.  SKM_CENTER=0 / 1 forces the answer."""
+    mode = os.environ.get("SKM_CENTER", "auto")
+    mean = np.asarray(mean, dtype=np.float64).reshape(-1)
+    if mode == "0" or not np.all(np.isfinite(mean)):
+        return None
+    if mode == "1":
+        return mean
+    std = np.asarray(std, dtype=np.float64).reshape(-1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        far = np.abs(mean) > 0.5 * std
+    return mean if bool(np.any(far & np.isfinite(std))) else None
 
 
 _default_engine = None

@@ -59,7 +59,12 @@ def gmm_scoring_singleThread(ubm, enroll, ndx, feature_server, score_mat, seg_id
             return
         X = eng.upload_frames(np.concatenate(blocks, axis=0))
     seg_off_dev = eng.torch.as_tensor(seg_off).to(eng.device)
-    ubm_mean = eng.segment_mean(eng.loglik(X, ubm._pack()), seg_off_dev)
+    # un-normalised features: every model is packed around the UBM's mean and the frames are centred once
+    # (log-likelihoods are translation invariant; Mixture._auto_shift)
+    shift = ubm._auto_shift()
+    if shift is not None:
+        X = eng.center_frames(X, shift)
+    ubm_mean = eng.segment_mean(eng.loglik(X, ubm._pack(shift=shift), centered=True), seg_off_dev)
 
     # models that take part in a trial of these segments AND are enrolled (gmm_scoring.py:87-93)
     mask = np.asarray(ndx.trialmask)[:, seg_idx]
@@ -69,9 +74,9 @@ def gmm_scoring_singleThread(ubm, enroll, ndx, feature_server, score_mat, seg_id
         if not mask[m].any() or model not in enr_index:
             continue
         packed = eng.pack(ubm.w, np.asarray(enroll.stat1[enr_index[model], :], dtype=np.float64).reshape(ubm.mu.shape),
-                          ubm.invcov)
+                          ubm.invcov, shift=shift)
         rows.append(m)
-        llr.append(eng.segment_mean(eng.loglik(X, packed), seg_off_dev) - ubm_mean)
+        llr.append(eng.segment_mean(eng.loglik(X, packed, centered=True), seg_off_dev) - ubm_mean)
     if not rows:
         return
     llr = eng.to_host(eng.torch.stack(llr))             # [models x segments]

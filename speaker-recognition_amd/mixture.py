@@ -32,6 +32,25 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+def _row_logsumexp(lp, engine=None):
+    """(pp, log_lk[T]) of a T x C matrix of log-probabilities, float64, on the GPU (skm_row_logsumexp)."""
+    eng = engine or _engine.default_engine()
+    lp = np.asarray(lp, dtype=np.float64)
+    if lp.ndim != 2:
+        raise ValueError("sum_log_probabilities wants a T x C matrix")
+    dev = eng.torch.from_numpy(np.ascontiguousarray(lp)).to(eng.device)
+    pp, log_lk = eng.row_logsumexp(dev)
+    return eng.to_host(pp), eng.to_host(log_lk)
+
+
+def sum_log_probabilities(lp, engine=None):
+    """Posteriors and the SUMMED log-likelihood of a matrix of log-probabilities (sidekit/mixture.py:52-64):
+    returns (pp, llk).  The training path never forms `lp` (the E-step kernels fuse this); this free function is for
+    callers that import it by name."""
+    pp, log_lk = _row_logsumexp(lp, engine)
+    return pp, log_lk.sum()
+
+
 class Mixture(object):
     """Gaussian mixture model storage + EM training (sidekit/mixture.py:67-197)."""
 
@@ -196,8 +215,24 @@ class Mixture(object):
         self._compute_all()
 
     # ------------------------------------------------------------------ E-step on the GPU
-    def _pack(self):
-        return self.engine.pack(self.w, self.mu, self.invcov)
+    def _auto_shift(self):
+        """Offset to centre the frames on when this model sits far from the origin (un-normalised features), else
+        None: the model's own mean sum_c w_c mu_c against its total standard deviation per dimension.  The kernels
+        accumulate logits in float32; centring keeps their magnitude at the spread of the model instead of its
+        distance from zero (engine.centering_offset, include/skm.h skm_frames_center)."""
+        if self.mu.ndim != 2 or self.mu.size == 0:
+            return None
+        w = self.w / np.sum(self.w)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            m = w @ self.mu
+            var = w @ (1.0 / self.invcov + np.square(self.mu)) - np.square(m)
+        off = _engine.centering_offset(m, np.sqrt(np.maximum(var, 0.0)))
+        return None if off is None else self.engine.frame_shift(off)
+
+    def _pack(self, shift="auto"):
+        if isinstance(shift, str):
+            shift = self._auto_shift()
+        return self.engine.pack(self.w, self.mu, self.invcov, shift=shift)
 
     def _device_frames(self, cep):
         """float32 device view of `cep` (uploads a host array; device tensors pass through)."""
@@ -241,9 +276,11 @@ class Mixture(object):
         out = None
         for feat in feature_list:
             X = self._device_frames(feature_server.load(feat)[0])
-            out = self.engine.estep(X, packed, out=out, accumulate=out is not None)
+            out = self.engine.estep(X, packed, out=out, accumulate=out is not None, unshift=False)
         if out is None:
             return
+        if packed.shift is not None:        # the correction is linear: once, on the sum over the files
+            self.engine.stats_unshift_(out, packed.C, packed.D, packed.shift)
         N, F, S, llk = self._unpack_stats(self.engine.to_host(out))
         stat_acc.w += N
         stat_acc.mu += F
@@ -316,6 +353,10 @@ class Mixture(object):
         self.det = np.zeros(self.w.shape)
         self.cov_var_ctl = 1.0 / copy.deepcopy(self.invcov)
         self._compute_all()
+        # un-normalised features: the EM loop runs on frames centred on the global mean (identical on every rank:
+        # it comes from the all-reduced moments)
+        off = _engine.centering_offset(mu, np.sqrt(np.maximum(cov - np.square(mu), 0.0)))
+        self._em_shift = None if off is None else self.engine.frame_shift(off)
         return X_dev
 
     def EM_split(self,
@@ -335,6 +376,9 @@ class Mixture(object):
         commented out, mixture.py:711-731)."""
         llk = []
         X_dev = self._init(features_server, feature_list, num_thread)
+        shift = self._em_shift
+        if shift is not None:
+            X_dev = self.engine.center_frames(X_dev, shift)
         selected = False
 
         for it in iterations[:int(np.log2(distrib_nb))]:
@@ -353,15 +397,17 @@ class Mixture(object):
                     if not (same is not None and same(feature_list)):
                         del X_dev
                         X_dev = self._resident_frames(features_server, feature_list)
-            llk.extend(self._em_iterations_device(X_dev, it, ceil_cov, floor_cov))
+                        if shift is not None:
+                            X_dev = self.engine.center_frames(X_dev, shift)
+            llk.extend(self._em_iterations_device(X_dev, it, ceil_cov, floor_cov, shift=shift))
         return llk
 
-    def _em_iterations_device(self, X_dev, it, ceil_cov=10, floor_cov=1e-2):
+    def _em_iterations_device(self, X_dev, it, ceil_cov=10, floor_cov=1e-2, shift=None):
         """`it` EM iterations of the loop body mixture.py:686-710 with the model resident on the GPU: E-step,
         all-reduce of the packed statistics, M-step + variance control + re-pack (skm_gmm_mstep_pack) -- no host
         round trip inside the loop.  The parameters and the per-iteration mean log-likelihoods come back once."""
         eng = self.engine
-        loop = _DeviceEM(self, X_dev, ceil_cov, floor_cov)
+        loop = _DeviceEM(self, X_dev, ceil_cov, floor_cov, shift=shift)
         llk_dev = eng.torch.empty(it, dtype=eng.torch.float64, device=eng.device)
         for i in range(it):
             loop.step(llk_mean=llk_dev[i:i + 1])
@@ -379,8 +425,11 @@ class Mixture(object):
             a, b = dist.shard_bounds(n_total)
             local = cep[a:b]
         X_dev = self._device_frames(local)
+        shift = self._auto_shift()          # from the initial model: the same on every rank
+        if shift is not None:
+            X_dev = self.engine.center_frames(X_dev, shift)
         # the model stays on the GPU; only the summed log-likelihood (8 bytes) is read per iteration for the gain test
-        loop = _DeviceEM(self, X_dev, 10, 1e-2)
+        loop = _DeviceEM(self, X_dev, 10, 1e-2, shift=shift)
         for i in range(0, iteration_max):
             stats = loop.step()
             llk.append(float(self.engine.to_host(stats[-1:])[0]) / n_total)
@@ -431,7 +480,8 @@ class Mixture(object):
         if mu is None:
             packed = self._pack()
         else:
-            packed = self.engine.pack(self.w, np.asarray(mu, dtype=np.float64).reshape(self.mu.shape), self.invcov)
+            packed = self.engine.pack(self.w, np.asarray(mu, dtype=np.float64).reshape(self.mu.shape), self.invcov,
+                                      shift=self._auto_shift())
         X = self._device_frames(cep)
         return self.engine.to_host(self.engine.logprob(X, packed))
 
@@ -449,17 +499,21 @@ class _DeviceEM(object):
     rank's frames, all-reduce of the packed statistics, M-step + variance control + re-pack on the device
     (skm_gmm_mstep_pack); download() brings the parameters back and refreshes det / cst / A."""
 
-    def __init__(self, mixture, X_dev, ceil_cov, floor_cov):
+    def __init__(self, mixture, X_dev, ceil_cov, floor_cov, shift=None):
+        """`shift`: X_dev holds frames centred on it (engine.center_frames); the loop then lives in the centred
+        coordinates -- the M-step is translation invariant (mu' = F'/N, cov = S'/N - mu'^2, same w, same llk) -- and
+        download() moves the means back."""
         eng = mixture.engine
         self.m, self.eng, self.X = mixture, eng, X_dev
         self.ceil, self.floor = ceil_cov, floor_cov
-        self.packed = mixture._pack()
+        self.shift = shift
+        self.packed = mixture._pack(shift=shift)
         self.ctl = eng.torch.from_numpy(np.ascontiguousarray(mixture.cov_var_ctl, dtype=np.float64)).to(eng.device)
         self.params = self.stats = None
 
     def step(self, llk_mean=None):
         """One iteration; returns the all-reduced statistics [N | F | S | llk] it was made from (device)."""
-        self.stats = self.eng.estep(self.X, self.packed, out=self.stats)
+        self.stats = self.eng.estep(self.X, self.packed, out=self.stats, centered=True, unshift=False)
         dist.allreduce_sum_(self.stats)
         self.params = self.eng.mstep_pack(self.stats, self.ctl, self.packed, self.ceil, self.floor,
                                           params=self.params, llk_mean=llk_mean)
@@ -473,6 +527,8 @@ class _DeviceEM(object):
         flat = self.eng.to_host(self.params)
         m.w = flat[:C].copy()
         m.mu = flat[C:C + C * D].reshape(C, D).copy()
+        if self.shift is not None:
+            m.mu += self.shift.host[None, :]
         m.invcov = flat[C + C * D:C + 2 * C * D].reshape(C, D).copy()
         m._compute_all()
 

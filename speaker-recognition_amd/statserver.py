@@ -22,6 +22,13 @@ from .mixture import Mixture, _h5
 STAT_TYPE = np.float64
 
 
+def sum_log_probabilities(lp, engine=None):
+    """Posteriors and the PER-FRAME log-likelihood of a matrix of log-probabilities (sidekit/statserver.py:83-95,
+    used by gmm_scoring.py:102-111): returns (pp, log_lk[T])."""
+    from .mixture import _row_logsumexp
+    return _row_logsumexp(lp, engine)
+
+
 class StatServer(object):
     def __init__(self, statserver_file_name=None, distrib_nb=0, feature_size=0, index=None, ubm=None,
                  engine=None):
@@ -214,7 +221,7 @@ class StatServer(object):
 
         eng = self.engine
         torch = eng.torch
-        packed = eng.pack(ubm.w, ubm.mu, ubm.invcov)
+        packed = ubm._pack()              # centred on the UBM's mean when it sits far from the origin (raw cepstra)
         C, D = ubm.distrib_nb(), ubm.dim()
         kept = []                         # (rows, stat0 f32, stat1 f32) device blocks when keep_on_device
 
@@ -271,7 +278,7 @@ class StatServer(object):
                 X = eng.upload_sessions(batch)          # pinned, pipelined; no host concatenation
             else:
                 X = eng.upload_frames(np.concatenate(batch, axis=0) if len(batch) > 1 else batch[0])
-            s0, s1 = eng.bw_stats(X, seg_off, packed)
+            s0, s1 = eng.bw_stats(X, seg_off, packed, own_frames=True)
             store(batch_idx, s0, s1)
 
         def show_of(idx):

@@ -10,9 +10,17 @@ from oracle import sidekit_ref as orc
 
 
 class _Packed(object):
-    def __init__(self, w, mu, invcov):
+    def __init__(self, w, mu, invcov, shift=None):
         self.gmm = orc.GMM(w, mu, invcov)
         self.C, self.D = self.gmm.C, self.gmm.D
+        self.shift = shift
+
+
+class _Shift(object):
+    """HipEngine's FrameShift: the float32 rounding of the offset, as float64."""
+    def __init__(self, m):
+        self.host = np.asarray(m, dtype=np.float64).reshape(-1).astype(np.float32).astype(np.float64)
+        self.D = self.host.size
 
 
 class OracleEngine(object):
@@ -28,8 +36,29 @@ class OracleEngine(object):
             a = a[:, None]
         return torch.from_numpy(np.ascontiguousarray(a))
 
-    def pack(self, w, mu, invcov):
-        return _Packed(w, mu, invcov)
+    def frame_shift(self, m):
+        return m if m is None or isinstance(m, _Shift) else _Shift(m)
+
+    def center_frames(self, X, shift, inplace=False):
+        out = (X.numpy() - shift.host.astype(np.float32)[None, :]).astype(np.float32)
+        if inplace:
+            X.copy_(torch.from_numpy(out))
+            return X
+        return torch.from_numpy(out)
+
+    def stats_unshift_(self, flat, C, D, shift):
+        a = flat.numpy()
+        N = a[:C].copy()
+        F = a[C:C + C * D].reshape(C, D).copy()
+        m = shift.host[None, :]
+        a[C:C + C * D] = (F + N[:, None] * m).ravel()
+        a[C + C * D:C + 2 * C * D] += (m * (2.0 * F + N[:, None] * m)).ravel()
+        return flat
+
+    def pack(self, w, mu, invcov, shift=None):
+        shift = self.frame_shift(shift)
+        mu = np.asarray(mu, dtype=np.float64)
+        return _Packed(w, mu if shift is None else mu - shift.host[None, :], invcov, shift)
 
     def mstep_pack(self, stats, cov_var_ctl, gmm, ceil_cov, floor_cov, params=None, llk_mean=None):
         """Oracle M-step (sidekit/mixture.py:590-611) on the packed statistics; `gmm` is updated in place."""
@@ -45,9 +74,13 @@ class OracleEngine(object):
             llk_mean[0] = flat[-1] / N.sum()
         return torch.from_numpy(np.concatenate([g.w, g.mu.ravel(), g.invcov.ravel(), [N.sum()]]))
 
-    def estep(self, X, gmm, out=None, accumulate=False):
+    def estep(self, X, gmm, out=None, accumulate=False, centered=False, unshift=True):
+        if gmm.shift is not None and not centered:
+            X = self.center_frames(X, gmm.shift)
         N, F, S, llk = orc.expectation(gmm.gmm, X.numpy().astype(np.float64))
         flat = torch.from_numpy(np.concatenate([N, F.ravel(), S.ravel(), [llk]]))
+        if gmm.shift is not None and unshift:
+            self.stats_unshift_(flat, gmm.C, gmm.D, gmm.shift)
         if out is not None and accumulate:
             out += flat
             return out
@@ -101,13 +134,19 @@ class OracleEngine(object):
         x = X.numpy().astype(np.float64)
         return torch.from_numpy(np.concatenate([x.sum(0), (x ** 2).sum(0)]))
 
-    def bw_stats(self, X, seg_off, gmm, stat0=None, stat1=None):
+    def bw_stats(self, X, seg_off, gmm, stat0=None, stat1=None, centered=False, own_frames=False):
+        if gmm.shift is not None and not centered:
+            X = self.center_frames(X, gmm.shift)
         x = X.numpy().astype(np.float64)
         off = np.asarray(seg_off)
         s0, s1 = orc.accumulate_stat(gmm.gmm, [x[off[i]:off[i + 1]] for i in range(len(off) - 1)])
+        if gmm.shift is not None:
+            s1 += np.repeat(s0, gmm.D, axis=1) * np.tile(gmm.shift.host, gmm.C)[None, :]
         return torch.from_numpy(s0), torch.from_numpy(s1)
 
-    def loglik(self, X, gmm):
+    def loglik(self, X, gmm, centered=False):
+        if gmm.shift is not None and not centered:
+            X = self.center_frames(X, gmm.shift)
         lp = orc.log_posterior(gmm.gmm, X.numpy().astype(np.float64))
         return torch.from_numpy(orc.logsumexp_rows(lp)[1].astype(np.float32))
 

@@ -11,26 +11,11 @@ import numpy as np
 import pytest
 
 from oracle import sidekit_ref as orc
-from conftest import golden
+from conftest import golden, rel, rel_large, rel_rows
 
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-
-
-def rel(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
-    assert a.shape == b.shape, (a.shape, b.shape)
-    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
-
-
-def rel_large(a, b, frac=0.05):
-    """worst element-wise relative error over entries with |ref| >= frac * max|ref|"""
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
-    m = np.abs(b) >= frac * np.abs(b).max()
-    return (np.abs(a - b)[m] / np.abs(b)[m]).max()
 
 
 @pytest.fixture(scope="module")
@@ -65,6 +50,8 @@ def test_estep_vs_reference_golden(eng, tag):
     assert rel_large(N, g["N"]) < TOL
     assert rel_large(F, g["F"]) < TOL
     assert rel_large(S, g["S"]) < TOL
+    # element-wise on the entries that carry their component's row (every N_c; F_c and S_c per component)
+    assert rel_rows(N, g["N"]) < TOL and rel_rows(F, g["F"]) < TOL and rel_rows(S, g["S"]) < TOL
     assert abs(llk - float(g["llk"])) < 1e-5 * abs(float(g["llk"]))
     # M-step from the device statistics reproduces the reference's next model
     orc.maximization(gmm, N, F, S)
@@ -103,6 +90,9 @@ def test_estep_vs_oracle_shapes(eng, C, D, T):
     assert rel(N, rN) < TOL
     assert rel(F, rF) < TOL
     assert rel(S, rS) < TOL
+    # north star: "within 1e-4 relative" -- element-wise on the entries that carry their component's row
+    rows = (rel_rows(N, rN), rel_rows(F, rF), rel_rows(S, rS))
+    assert max(rows) < TOL, rows
     assert abs(llk - rl) < 1e-5 * abs(rl)
     assert abs(N.sum() - T) < 1e-4 * T          # posteriors sum to one per frame
 
@@ -151,6 +141,7 @@ def test_bw_stats_vs_reference_golden(eng):
     assert rel(s0, g["stat0"]) < TOL
     assert rel(s1, g["stat1"]) < TOL
     assert rel_large(s0, g["stat0"]) < TOL and rel_large(s1, g["stat1"]) < TOL     # element-wise on the entries that matter
+    assert rel_rows(s0, g["stat0"]) < TOL and rel_rows(s1, g["stat1"]) < TOL       # ... of every session's row
     # per-session normwise too (short sessions must be as accurate as long ones)
     for i in range(len(sess)):
         assert rel(s0[i], g["stat0"][i]) < TOL
@@ -167,6 +158,7 @@ def test_bw_stats_ragged_and_empty_sessions(eng):
     s0, s1 = eng.to_host(s0), eng.to_host(s1)
     r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
     assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
+    assert rel_rows(s0, r0) < TOL and rel_rows(s1, r1) < TOL, (rel_rows(s0, r0), rel_rows(s1, r1))
     assert np.all(s0[0] == 0) and np.all(s1[5] == 0)
     assert np.allclose(s0.sum(1), lens, rtol=1e-4)
 
@@ -188,6 +180,7 @@ def test_bw_stats_team_kernel_ragged_and_empty_sessions(eng, C, D):
     s0, s1 = eng.to_host(s0), eng.to_host(s1)
     r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
     assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
+    assert rel_rows(s0, r0) < TOL and rel_rows(s1, r1) < TOL, (rel_rows(s0, r0), rel_rows(s1, r1))
     for i, n in enumerate(lens):
         if n == 0:
             assert np.all(s0[i] == 0) and np.all(s1[i] == 0)
@@ -223,6 +216,7 @@ def test_bw_stats_small_blocks_and_wide_rows(eng, C, D):
     s0, s1 = eng.to_host(s0), eng.to_host(s1)
     r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
     assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
+    assert rel_rows(s0, r0) < TOL and rel_rows(s1, r1) < TOL, (rel_rows(s0, r0), rel_rows(s1, r1))
     for i, n in enumerate(lens):
         if n == 0:
             assert np.all(s0[i] == 0) and np.all(s1[i] == 0)
@@ -315,6 +309,7 @@ def test_statserver_accumulate_stat_dropin(sk):
     assert ss.validate()
     assert rel(ss.stat0, g["stat0"]) < TOL
     assert rel(ss.stat1, g["stat1"]) < TOL
+    assert rel_rows(ss.stat0, g["stat0"]) < TOL and rel_rows(ss.stat1, g["stat1"]) < TOL
     with pytest.raises(Exception):
         bad = sk.FeaturesServer(features={n: np.zeros((5, ubm.dim() + 1)) for n in names})
         ss.accumulate_stat(ubm=ubm, feature_server=bad, seg_indices=range(2))
@@ -364,6 +359,9 @@ def test_em_split_dropin_vs_reference_golden(sk):
     assert rel(ubm.w, g["w"]) < TOL
     assert rel(ubm.mu, g["mu"]) < TOL
     assert rel(1.0 / ubm.invcov, 1.0 / g["invcov"]) < TOL
+    # UBM w / mu / covariance element-wise (per component, the entries that carry the row)
+    assert rel_rows(ubm.w, g["w"]) < TOL and rel_rows(ubm.mu, g["mu"]) < TOL
+    assert rel_rows(1.0 / ubm.invcov, 1.0 / g["invcov"]) < TOL
     assert rel(ubm.cov_var_ctl, g["ctl"]) < 1e-6
     assert ubm.validate()
 
@@ -377,6 +375,9 @@ def test_em_uniform_dropin_vs_reference_golden(sk):
     assert rel(ubm.w, g["w"]) < TOL
     assert rel(ubm.mu, g["mu"]) < TOL
     assert rel(1.0 / ubm.invcov, 1.0 / g["invcov"]) < TOL
+    # UBM w / mu / covariance element-wise (per component, the entries that carry the row)
+    assert rel_rows(ubm.w, g["w"]) < TOL and rel_rows(ubm.mu, g["mu"]) < TOL
+    assert rel_rows(1.0 / ubm.invcov, 1.0 / g["invcov"]) < TOL
 
 
 def test_one_em_step_from_identical_params_large(sk, eng):

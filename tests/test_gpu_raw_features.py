@@ -1,0 +1,172 @@
+"""Un-normalised, raw-MFCC-like features (per-dimension offsets up to +-30, variances 1..100, no cmvn) through the
+drop-in classes and the C ABI: golden vectors of the REAL reference (tools/gen_golden.py raw ->
+tests/golden/raw_features.npz: Mixture._expectation mixture.py:537-568, StatServer.accumulate_stat
+statserver.py:609-667, EM_split) and the oracle on more shapes.
+
+The kernels accumulate logits in float32; on frames that sit tens of standard deviations from the origin the logits
+reach the thousands and the posteriors lose the 1e-4 bar.  The path is translation invariant, so the drop-in classes
+centre such frames (engine.centering_offset, skm_frames_center) and map the statistics back exactly
+(skm_gmm_stats_unshift / skm_bw_unshift).  Bar: 1e-4 ELEMENT-WISE on the entries that carry their row."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sidekit_ref as orc
+from conftest import golden, rel, rel_rows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def sk():
+    import sidekit_amd
+    return sidekit_amd
+
+
+@pytest.fixture(scope="module")
+def eng(sk):
+    return sk.default_engine()
+
+
+def make_ubm(sk, w, mu, invcov):
+    m = sk.Mixture()
+    m.w, m.mu, m.invcov = np.array(w), np.array(mu), np.array(invcov)
+    m.cov_var_ctl = 1.0 / m.invcov
+    m._compute_all()
+    return m
+
+
+def mem_server(sk, table):
+    return sk.FeaturesServer(features=table)
+
+
+def test_expectation_raw_vs_reference_golden(sk):
+    g = golden("raw_features.npz")
+    ubm = make_ubm(sk, g["w"], g["mu"], g["invcov"])
+    assert ubm._auto_shift() is not None, "this model sits far from the origin: the frames must be centred"
+    accum = make_ubm(sk, g["w"], g["mu"], g["invcov"])
+    accum._reset()
+    llk = ubm._expectation(accum, g["cep"])
+    for got, ref in ((accum.w, g["N"]), (accum.mu, g["F"]), (accum.invcov, g["S"])):
+        assert rel(got, ref) < TOL
+        assert rel_rows(got, ref) < TOL
+    assert abs(llk - float(g["llk"])) < 1e-6 * abs(float(g["llk"]))
+    # the T x C matrix and the per-frame log-likelihood of the same frames
+    lp = ubm.compute_log_posterior_probabilities(g["cep"][:200])
+    top = g["lp200"] >= g["lp200"].max(axis=1, keepdims=True) - 30.0        # the components that carry the frame
+    assert np.abs(lp - g["lp200"])[top].max() < 1e-4
+    assert np.abs(ubm.log_likelihood(g["cep"]) - g["log_lk"]).max() < 1e-4
+
+
+def test_accumulate_stat_raw_vs_reference_golden(sk):
+    g = golden("raw_features.npz")
+    ubm = make_ubm(sk, g["w"], g["mu"], g["invcov"])
+    off = np.concatenate([[0], np.cumsum(g["bw_lens"])])
+    names = ["r%03d" % i for i in range(len(g["bw_lens"]))]
+    table = {n: g["bw_frames"][off[i]:off[i + 1]] for i, n in enumerate(names)}
+    idmap = sk.IdMap()
+    idmap.leftids = np.array(["spk%d" % (i % 5) for i in range(len(names))])
+    idmap.rightids = np.array(names)
+    idmap.start = np.empty(len(names), "|O")
+    idmap.stop = np.empty(len(names), "|O")
+    ss = sk.StatServer(idmap, ubm=ubm)
+    ss.accumulate_stat(ubm=ubm, feature_server=mem_server(sk, table), seg_indices=range(len(names)))
+    assert rel(ss.stat0, g["stat0"]) < TOL and rel(ss.stat1, g["stat1"]) < TOL
+    assert rel_rows(ss.stat0, g["stat0"]) < TOL          # per session, the components that carry it
+    assert rel_rows(ss.stat1, g["stat1"]) < TOL
+    C, D = ubm.distrib_nb(), ubm.dim()
+    # per (session, component) row of first-order statistics, for the components that hold >= 1 % of the session
+    s1, r1 = ss.stat1.reshape(-1, D), g["stat1"].reshape(-1, D)
+    keep = (g["stat0"] >= 0.01 * g["stat0"].sum(1, keepdims=True)).reshape(-1)
+    assert rel_rows(s1[keep], r1[keep]) < TOL
+
+
+def test_em_split_raw_vs_reference_golden(sk):
+    g = golden("raw_features.npz")
+    table = {"f%d" % i: g["em_chunk%d" % i] for i in range(3)}
+    ubm = sk.Mixture()
+    llk = ubm.EM_split(features_server=mem_server(sk, table), feature_list=list(table.keys()), distrib_nb=8)
+    assert ubm._em_shift is not None
+    assert len(llk) == len(g["em_llk"])
+    assert np.abs(np.array(llk) - g["em_llk"]).max() < 1e-5 * np.abs(g["em_llk"]).max()
+    assert rel(ubm.w, g["em_w"]) < TOL and rel_rows(ubm.w, g["em_w"]) < TOL
+    assert rel(ubm.mu, g["em_mu"]) < TOL and rel_rows(ubm.mu, g["em_mu"]) < TOL
+    assert rel(1.0 / ubm.invcov, 1.0 / g["em_invcov"]) < TOL and rel_rows(1.0 / ubm.invcov, 1.0 / g["em_invcov"]) < TOL
+
+
+# one shape per kernel family: one-wave (C <= 128), fat (C = 512), wide rows, team (C = 2048), two sweeps (C = 600)
+@pytest.mark.parametrize("C,D,T", [(64, 60, 5000), (512, 60, 20000), (64, 132, 4000), (2048, 60, 8000), (600, 39, 6000),
+                                   (128, 20, 3000)])
+def test_centred_c_abi_vs_oracle_shapes(eng, C, D, T):
+    """skm_frames_center + skm_gmm_pack on the shifted means + skm_gmm_estep + skm_gmm_stats_unshift, and the same for
+    skm_bw_stats / skm_bw_unshift, against the float64 oracle on the un-shifted frames."""
+    gmm = orc.raw_gmm(C, D, seed=C + D)
+    cep = orc.synth_raw_frames(T, dim=D, clusters=16, seed=T)
+    x64 = cep.astype(np.float64)
+    shift = eng.frame_shift(gmm.w @ gmm.mu)
+    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov, shift=shift)
+    X = eng.upload_frames(cep)
+    flat = eng.to_host(eng.estep(X, packed))
+    N, F, S, llk = flat[:C], flat[C:C + C * D].reshape(C, D), flat[C + C * D:C + 2 * C * D].reshape(C, D), flat[-1]
+    rN, rF, rS, rl = orc.expectation(gmm, x64)
+    for got, ref in ((N, rN), (F, rF), (S, rS)):
+        assert rel(got, ref) < TOL
+        assert rel_rows(got, ref) < TOL
+    assert abs(llk - rl) < 1e-6 * abs(rl)
+    # accumulate: two halves added on the device equal the whole
+    out = eng.estep(X[:T // 3].contiguous(), packed)
+    out = eng.estep(X[T // 3:].contiguous(), packed, out=out, accumulate=True)
+    assert rel(eng.to_host(out), flat) < 1e-6
+    rs = np.random.RandomState(T)
+    cuts = np.sort(rs.choice(np.arange(1, T), size=12, replace=False))
+    off = np.concatenate([[0], cuts, [T]])
+    s0, s1 = eng.bw_stats(X, off, packed)
+    s0, s1 = eng.to_host(s0), eng.to_host(s1)
+    r0, r1 = orc.accumulate_stat(gmm, [x64[off[i]:off[i + 1]] for i in range(len(off) - 1)])
+    assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
+    assert rel_rows(s0, r0) < TOL and rel_rows(s1, r1) < TOL
+    ll = eng.to_host(eng.loglik(X, packed)).astype(np.float64)
+    rll = orc.logsumexp_rows(orc.log_posterior(gmm, x64))[1]
+    assert np.abs(ll - rll).max() < 1e-5 * np.abs(rll).max()
+
+
+def test_centring_is_what_makes_raw_features_pass(eng):
+    """The same frames WITHOUT centring miss the bar (why the path exists), and cmvn-like data are left alone."""
+    gmm = orc.raw_gmm(64, 60, seed=41)
+    cep = orc.synth_raw_frames(3000, dim=60, clusters=24, seed=42)
+    rN, rF, rS, _ = orc.expectation(gmm, cep.astype(np.float64))
+    X = eng.upload_frames(cep)
+    plain = eng.to_host(eng.estep(X, eng.pack(gmm.w, gmm.mu, gmm.invcov)))
+    centred = eng.to_host(eng.estep(X, eng.pack(gmm.w, gmm.mu, gmm.invcov, shift=gmm.w @ gmm.mu)))
+    e_plain = rel_rows(plain[64:64 + 64 * 60].reshape(64, 60), rF)
+    e_centred = rel_rows(centred[64:64 + 64 * 60].reshape(64, 60), rF)
+    assert e_centred < TOL
+    assert e_plain > 3 * e_centred, (e_plain, e_centred)
+    import sidekit_amd as sk
+    m = sk.Mixture()
+    g = orc.random_gmm(64, 60, seed=1)
+    m.w, m.mu, m.invcov = g.w, g.mu, g.invcov
+    assert m._auto_shift() is None
+
+
+def test_sum_log_probabilities_free_functions(sk):
+    """sidekit/mixture.py:52-64 (pp, summed llk) and sidekit/statserver.py:83-95 (pp, per-frame log_lk) on a matrix
+    the caller holds, rows without a finite maximum included."""
+    from importlib import import_module
+    g = golden("estep_c8_d6.npz")
+    lp = g["lp"].copy()
+    pp, llk = sk.sum_log_probabilities(lp)
+    assert rel(pp, g["pp"]) < 1e-12 and abs(llk - float(g["llk"])) < 1e-12 * abs(float(g["llk"]))
+    pp2, log_lk = import_module("speaker-recognition_amd.statserver").sum_log_probabilities(lp)
+    assert rel(pp2, g["pp"]) < 1e-12 and rel(log_lk, g["log_lk"]) < 1e-12
+    lp[3, :] = -np.inf
+    lp[5, 2] = np.nan
+    with np.errstate(invalid="ignore"):
+        rpp, rll = orc.logsumexp_rows(lp)
+    pp3, ll3 = import_module("speaker-recognition_amd.statserver").sum_log_probabilities(lp)
+    assert ll3[3] == -np.inf and np.isnan(ll3[5])
+    np.testing.assert_array_equal(np.isnan(pp3), np.isnan(rpp))
+    ok = ~np.isnan(rpp)
+    assert np.abs(pp3[ok] - rpp[ok]).max() < 1e-12

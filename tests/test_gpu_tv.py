@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import sidekit_ref as orc
+from conftest import rel_rows
 from conftest import golden
 
 pytestmark = pytest.mark.gpu
@@ -344,6 +345,9 @@ def test_random_tv_shapes_vs_oracle(eng, seed):
     assert rel(_upper_packed(A[:C]), rA) < 1e-4 and rel(Cc, rC) < 1e-4 and rel(_upper_packed(A[C]), rR) < 1e-4, what
     iv, iv_sigma = orc.extract_ivectors(s0, s1, gmm, Fm)
     assert rel(e_h, iv) < 1e-4 and rel(sig, iv_sigma) < 1e-4 and min_cosine(e_h, iv) > 0.9999, what
+    # element-wise on the entries that carry their row: A per component, C per factor, one i-vector per session
+    rows = (rel_rows(_upper_packed(A[:C]), rA), rel_rows(Cc, rC), rel_rows(e_h, iv), rel_rows(sig, iv_sigma))
+    assert max(rows) < 1e-4, (what, rows)
     ft, naug = eng.tv_whiten(dev(eng, s0), dev(eng, s1), gmm.mu.flatten(), gmm.invcov.flatten())
     T32, G = eng.tv_prepare(dev(eng, Fm), C, D)
     e_s, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=False)

@@ -693,8 +693,64 @@ def gen_full_plda(sidekit):
     print("full_plda", sc.scoremat.shape, list(sc.modelset))
 
 
+def gen_raw(sidekit):
+    """Un-normalised, raw-MFCC-like frames (per-dimension offsets up to +-30, variances 1..100, no cmvn): one
+    Mixture._expectation (mixture.py:537-568) and one StatServer.accumulate_stat (statserver.py:609-667), plus a
+    short EM_split, for the frame-centring path (round 3)."""
+    import copy
+    C, D, T = 64, 60, 2000
+    g = orc.raw_gmm(C, D, seed=41)
+    cep = orc.synth_raw_frames(T, dim=D, clusters=24, seed=42, dtype=np.float32).astype(np.float64)
+    ubm = make_ubm(sidekit, g.w, g.mu, g.invcov)
+    accum = copy.deepcopy(ubm)
+    accum._reset()
+    llk = ubm._expectation(accum, cep)
+    lp = ubm.compute_log_posterior_probabilities(cep[:200])
+    _, log_lk = sidekit.statserver.sum_log_probabilities(ubm.compute_log_posterior_probabilities(cep))
+    out = dict(w=ubm.w, mu=ubm.mu, invcov=ubm.invcov, cep=cep.astype(np.float32), N=accum.w.copy(), F=accum.mu.copy(),
+               S=accum.invcov.copy(), llk=np.float64(llk), lp200=lp, log_lk=log_lk)
+    # Baum-Welch statistics of ragged sessions of the same kind of data
+    rs = np.random.RandomState(43)
+    lens = [1, 5, 33, 64, 150] + list(rs.randint(30, 250, size=15))
+    table = {"r%03d" % i: orc.synth_raw_frames(L, dim=D, clusters=24, seed=200 + i, dtype=np.float32).astype(np.float64)
+             for i, L in enumerate(lens)}
+    fs = mem_server(sidekit, table)
+    S = len(lens)
+    idmap = sidekit.IdMap()
+    idmap.leftids = np.array(["spk%d" % (i % 5) for i in range(S)])
+    idmap.rightids = np.array(sorted(table.keys()))
+    idmap.start = np.empty(S, "|O")
+    idmap.stop = np.empty(S, "|O")
+    ss = sidekit.StatServer(idmap, ubm=ubm)
+    ss.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(S), num_thread=1)
+    out.update(bw_lens=np.array(lens), bw_frames=np.vstack([table[k] for k in sorted(table.keys())]).astype(np.float32),
+               stat0=ss.stat0.copy(), stat1=ss.stat1.copy())
+    # EM_split to 8 components on well-separated raw-scale clusters (split arg-max stays robust)
+    rs = np.random.RandomState(44)
+    D2, K = 8, 8
+    off = rs.uniform(-30, 30, size=D2)
+    centers = off + rs.randn(K, D2) * 12.0
+    sd = np.sqrt(np.exp(rs.uniform(0.0, np.log(9.0), size=(K, D2))))
+    chunks = {}
+    for i in range(3):
+        lab = rs.randint(0, K, size=700 + 41 * i)
+        chunks["f%d" % i] = (centers[lab] + sd[lab] * rs.randn(lab.shape[0], D2)).astype(np.float32).astype(np.float64)
+    fs2 = mem_server(sidekit, chunks)
+    u = sidekit.Mixture()
+    llk_em = u.EM_split(features_server=fs2, feature_list=list(chunks.keys()), distrib_nb=8, num_thread=1,
+                        save_partial=False)
+    for i in range(3):
+        out["em_chunk%d" % i] = chunks["f%d" % i].astype(np.float32)
+    out.update(em_llk=np.array(llk_em), em_w=u.w, em_mu=u.mu, em_invcov=u.invcov)
+    np.savez_compressed(os.path.join(OUT, "raw_features.npz"), **out)
+    print("raw_features: llk", llk, "stat0", ss.stat0.shape, "EM_split llk", llk_em[-2:])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "raw":
+        gen_raw(import_reference())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "round2":
         sidekit = import_reference()
         gen_em_split_vad(sidekit)
@@ -742,6 +798,7 @@ def main():
         gen_tv_big(sidekit, tmp)
         gen_plda(sidekit, tmp)
     gen_full_plda(sidekit)
+    gen_raw(sidekit)
 
 
 if __name__ == "__main__":
