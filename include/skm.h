@@ -63,18 +63,32 @@ size_t skm_gmm_packed_bytes(int C, int D);
 int skm_gmm_pack(void *ctx, const double *w_host, const double *mu_host, const double *invcov_host,
                  int C, int D, void *packed_dev, void *stream);
 
+/* The same image RELATIVE TO A REFERENCE GAUSSIAN R = N(0, diag(1 / ref_invvar)) (ref_invvar_host: D doubles, the
+ * inverse of the per-dimension variance of all the data or of the whole model; an entry <= 0 leaves its dimension
+ * alone; NULL = skm_gmm_pack): square rows -1/2 (invcov - ref_invvar), kc without log R's constant, so the logit
+ * the kernels accumulate is log2(w_c N_c(x) / R(x)).  R(x) is common to all components of a frame: posteriors, N, F,
+ * S and the Baum-Welch statistics are unchanged, while the float32 partial sums lose their largest part (x^2 / v
+ * summed over the dimensions) and with it most of their rounding error -- the reference forms the same logits in
+ * float64 (sidekit/mixture.py:482-486).  What is NOT unchanged: skm_gmm_estep's llk is then sum_t log(p(x_t) / R(x_t))
+ * and skm_gmm_llk_ref adds sum_t log R(x_t) back from the statistics themselves (T frames; in place, before any
+ * skm_gmm_stats_unshift); skm_gmm_loglik / skm_gmm_logprob give per-frame values and want a plain image. */
+int skm_gmm_pack_ref(void *ctx, const double *w_host, const double *mu_host, const double *invcov_host,
+                     const double *ref_invvar_host, int C, int D, void *packed_dev, void *stream);
+int skm_gmm_llk_ref(void *ctx, double *stats_dev, int C, int D, long T, const double *ref_invvar_dev, void *stream);
+
 /* M-step and re-pack on the device, so that an EM iteration needs no host round trip:
  *   stats_dev        [ N | F | S | llk ] as skm_gmm_estep leaves it (after the all-reduce in a multi-GPU run)
  *   cov_var_ctl_dev  C*D float64, the variance-control reference of the model (sidekit/mixture.py:636-640)
  *   params_dev       out: [ w (C) | mu (C*D) | invcov (C*D) | sum N ] float64
  *   packed_dev       out: the image skm_gmm_pack would build from those parameters
  *   llk_mean_dev     out (optional): llk / sum N, the value EM_split appends per iteration (mixture.py:706)
+ *   ref_invvar_dev   D doubles on the device or NULL: re-pack relative to that reference Gaussian (skm_gmm_pack_ref)
  * w = N / sum N, mu = F / N, cov = S / N - mu^2 clamped to [floor_cov, ceil_cov] * cov_var_ctl with the reference's
  * inclusive comparisons, invcov = 1 / cov.  Replaces Mixture._maximization + variance_control + _compute_all
  * (sidekit/mixture.py:590-611, 489-506, 382-396) inside the EM loop; float64 throughout. */
 int skm_gmm_mstep_pack(void *ctx, const double *stats_dev, const double *cov_var_ctl_dev, int C, int D,
                        double ceil_cov, double floor_cov, double *params_dev, void *packed_dev,
-                       double *llk_mean_dev, void *stream);
+                       double *llk_mean_dev, const double *ref_invvar_dev, void *stream);
 
 /* Workspace bytes for skm_gmm_estep / skm_gmm_loglik / skm_bw_stats over T frames. */
 size_t skm_gmm_workspace_bytes(void *ctx, long T, int C, int D);

@@ -284,8 +284,18 @@ extern "C" size_t skm_gmm_packed_bytes(int C, int D)
     return ((size_t)g.CTpad * g.NCH * 256 + (size_t)g.CTpad * 32) * sizeof(float);
 }
 
+// Image relative to a reference Gaussian R = N(0, diag(1 / riv)) (skm_gmm_pack_ref, include/skm.h): the square rows
+// hold -1/2 (invcov - riv) and kc drops log R's constant, so the kernels' logit is log2(w_c N_c(x) / R(x)).  A
+// per-frame term common to all components changes neither the posteriors nor N / F / S; what it changes is the size
+// of the float32 partial sums (the x^2 / v part of every logit, about D/2 nats, is gone), i.e. their rounding error.
 extern "C" int skm_gmm_pack(void *ctx, const double *w, const double *mu, const double *ic, int C, int D,
                             void *packed_dev, void *stream)
+{
+    return skm_gmm_pack_ref(ctx, w, mu, ic, nullptr, C, D, packed_dev, stream);
+}
+
+extern "C" int skm_gmm_pack_ref(void *ctx, const double *w, const double *mu, const double *ic, const double *riv,
+                                int C, int D, void *packed_dev, void *stream)
 {
     SKM_REQUIRE(ctx && w && mu && ic && packed_dev, "skm_gmm_pack: NULL argument");
     SKM_REQUIRE(C > 0 && D > 0, "skm_gmm_pack: bad shape C=%d D=%d", C, D);
@@ -309,19 +319,19 @@ extern "C" int skm_gmm_pack(void *ctx, const double *w, const double *mu, const 
                     double v = 0.0;
                     if (comp < C && d < D) {
                         const double icv = ic[(size_t)comp * D + d];
-                        v = kind ? (-0.5 * LOG2E * icv) : (LOG2E * mu[(size_t)comp * D + d] * icv);
+                        v = kind ? (-0.5 * LOG2E * (icv - (riv ? riv[d] : 0.0))) : (LOG2E * mu[(size_t)comp * D + d] * icv);
                     }
                     wp[(((size_t)tile * g.NCH + grp) * 64 + lane) * 4 + i] = (float)v;
                 }
             }
-    const double half_d_log2pi = 0.5 * D * log(2.0 * M_PI);
+    const double half_d_log2pi = riv ? 0.0 : 0.5 * D * log(2.0 * M_PI);
     for (int comp = 0; comp < g.CTpad * 32; ++comp) {
         double v = -1.0e30;
         if (comp < C) {
             double logdet_inv = 0.0, quad = 0.0;
             for (int d = 0; d < D; ++d) {
                 const double icv = ic[(size_t)comp * D + d], m = mu[(size_t)comp * D + d];
-                logdet_inv += log(icv);
+                logdet_inv += (riv && riv[d] > 0.0) ? log(icv / riv[d]) : log(icv);
                 quad += m * m * icv;
             }
             v = LOG2E * (log(w[comp]) + 0.5 * logdet_inv - half_d_log2pi - 0.5 * quad);
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256) void k_mstep_params(const double *__restrict__
 
 // the packed image of skm_gmm_pack, from parameters in device memory
 __global__ __launch_bounds__(256) void k_pack_w(const double *__restrict__ params, int C, int D, int CTpad, int NCH, int NP,
-                                                 float *__restrict__ wp)
+                                                 float *__restrict__ wp, const double *__restrict__ riv)
 {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;      // ((tile * NCH + grp) * 64 + lane) * 4 + i
     if (e >= (long)CTpad * NCH * 256) return;
@@ -399,14 +409,14 @@ __global__ __launch_bounds__(256) void k_pack_w(const double *__restrict__ param
     double v = 0.0;
     if (comp < C && d < D) {
         const double icv = params[(size_t)C + (size_t)C * D + (size_t)comp * D + d];
-        v = kind ? (-0.5 * 1.4426950408889634074 * icv)
+        v = kind ? (-0.5 * 1.4426950408889634074 * (icv - (riv ? riv[d] : 0.0)))
                  : (1.4426950408889634074 * params[(size_t)C + (size_t)comp * D + d] * icv);
     }
     wp[e] = (float)v;
 }
 
 __global__ __launch_bounds__(256) void k_pack_kc(const double *__restrict__ params, int C, int D, int ncomp,
-                                                  float *__restrict__ kc)
+                                                  float *__restrict__ kc, const double *__restrict__ riv)
 {
     const int comp = blockIdx.x * blockDim.x + threadIdx.x;
     if (comp >= ncomp) return;
@@ -415,10 +425,11 @@ __global__ __launch_bounds__(256) void k_pack_kc(const double *__restrict__ para
         const double *mu = params + C + (size_t)comp * D, *ic = params + C + (size_t)C * D + (size_t)comp * D;
         double logdet_inv = 0.0, quad = 0.0;
         for (int d = 0; d < D; ++d) {
-            logdet_inv += log(ic[d]);
+            logdet_inv += (riv && riv[d] > 0.0) ? log(ic[d] / riv[d]) : log(ic[d]);
             quad += mu[d] * mu[d] * ic[d];
         }
-        v = 1.4426950408889634074 * (log(params[comp]) + 0.5 * logdet_inv - 0.5 * D * log(2.0 * M_PI) - 0.5 * quad);
+        v = 1.4426950408889634074 *
+            (log(params[comp]) + 0.5 * logdet_inv - (riv ? 0.0 : 0.5 * D * log(2.0 * M_PI)) - 0.5 * quad);
         if (!(v > -1.0e30)) v = -1.0e30;  // w = 0 or NaN: component never wins
     }
     kc[comp] = (float)v;
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(256) void k_pack_kc(const double *__restrict__ para
 
 extern "C" int skm_gmm_mstep_pack(void *ctx_, const double *stats_dev, const double *cov_var_ctl_dev, int C, int D,
                                   double ceil_cov, double floor_cov, double *params_dev, void *packed_dev,
-                                  double *llk_mean_dev, void *stream)
+                                  double *llk_mean_dev, const double *ref_invvar_dev, void *stream)
 {
     SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
     SKM_REQUIRE(ctx && stats_dev && cov_var_ctl_dev && params_dev && packed_dev, "skm_gmm_mstep_pack: NULL argument");
@@ -440,8 +451,9 @@ extern "C" int skm_gmm_mstep_pack(void *ctx_, const double *stats_dev, const dou
     hipLaunchKernelGGL(k_mstep_params, dim3((unsigned)(((long)C * D + 255) / 256)), dim3(256), 0, st, stats_dev,
                        cov_var_ctl_dev, C, D, ceil_cov, floor_cov, params_dev);
     hipLaunchKernelGGL(k_pack_w, dim3((unsigned)(((long)g.CTpad * g.NCH * 256 + 255) / 256)), dim3(256), 0, st, params_dev, C, D,
-                       g.CTpad, g.NCH, g.NP, wp);
-    hipLaunchKernelGGL(k_pack_kc, dim3((g.CTpad * 32 + 255) / 256), dim3(256), 0, st, params_dev, C, D, g.CTpad * 32, kc);
+                       g.CTpad, g.NCH, g.NP, wp, ref_invvar_dev);
+    hipLaunchKernelGGL(k_pack_kc, dim3((g.CTpad * 32 + 255) / 256), dim3(256), 0, st, params_dev, C, D, g.CTpad * 32, kc,
+                       ref_invvar_dev);
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }
@@ -1374,6 +1386,41 @@ extern "C" int skm_moments(void *ctx_, const float *X, long T, int D, double *ou
 // The shift every kernel applies is the float32 rounding of shift[d] (so that x - m is the same number on both
 // sides of the identity); the host packs the model with the same rounded value.
 // ------------------------------------------------------------------------------------------------
+// Log-likelihood of an E-step run on an image relative to the reference Gaussian R = N(0, diag(1 / riv)): the kernels
+// summed log(p(x_t) / R(x_t)); sum_t log R(x_t) = T (-D/2 log 2 pi + 1/2 sum_d log riv_d) - 1/2 sum_d riv_d sum_t x_td^2,
+// and sum_t x_td^2 = sum_c S_cd because the posteriors of a frame sum to one.  One workgroup, fixed order, float64.
+__global__ __launch_bounds__(256) void k_llk_ref(double *__restrict__ stats, int C, int D, double T,
+                                                 const double *__restrict__ riv)
+{
+    __shared__ double part[256];
+    const double *S = stats + (size_t)C + (size_t)C * D;
+    double acc = 0.0;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        double col = 0.0;
+        for (int c = 0; c < C; ++c) col += S[(size_t)c * D + d];
+        const double r = riv[d];
+        acc += (r > 0.0 ? 0.5 * T * log(r) : 0.0) - 0.5 * r * col;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) part[threadIdx.x] += part[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) stats[(size_t)C + 2 * (size_t)C * D] += part[0] - 0.5 * T * D * log(2.0 * M_PI);
+}
+
+extern "C" int skm_gmm_llk_ref(void *ctx_, double *stats_dev, int C, int D, long T, const double *ref_invvar_dev,
+                               void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && stats_dev && ref_invvar_dev && C > 0 && D > 0 && T >= 0, "skm_gmm_llk_ref: bad argument");
+    SkmProfScope ps(ctx, "k_llk_ref", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_llk_ref, dim3(1), dim3(256), 0, (hipStream_t)stream, stats_dev, C, D, (double)T, ref_invvar_dev);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
 __global__ __launch_bounds__(256) void k_frames_center(const float *__restrict__ X, long n, int D,
                                                        const double *__restrict__ shift, float *__restrict__ out)
 {

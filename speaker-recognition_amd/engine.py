@@ -32,8 +32,10 @@ SIGNATURES = {
     "skm_prof_read": (_c_long, [_c_void_p, ctypes.c_char_p, _c_size_t]),
     "skm_gmm_packed_bytes": (_c_size_t, [_c_int, _c_int]),
     "skm_gmm_pack": (_c_int, [_c_void_p, _dp, _dp, _dp, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "skm_gmm_pack_ref": (_c_int, [_c_void_p, _dp, _dp, _dp, _dp, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "skm_gmm_llk_ref": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_long, _c_void_p, _c_void_p]),
     "skm_gmm_mstep_pack": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, ctypes.c_double, ctypes.c_double,
-                                    _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+                                    _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "skm_gmm_workspace_bytes": (_c_size_t, [_c_void_p, _c_long, _c_int, _c_int]),
     "skm_gmm_estep": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                                _c_void_p, _c_size_t, _c_void_p]),
@@ -240,10 +242,15 @@ class HipEngine(object):
                                             _c_void_p(shift.dev.data_ptr()), self._stream()))
         return stat1
 
-    def pack(self, w, mu, invcov, shift=None):
-        """Device image of the model.  With `shift` (a FrameShift) the image is the model of the CENTRED frames
-        x - shift (means mu - shift): estep / bw_stats / loglik / logprob then centre the frames they are given
-        (or take them as already centred, `centered=True`) and map the statistics back."""
+    def pack(self, w, mu, invcov, shift=None, ref_var=None):
+        """Device image of the model.
+        `shift` (a FrameShift or a D-vector): the image is the model of the CENTRED frames x - shift (means
+        mu - shift); estep / bw_stats / loglik / logprob then centre the frames they are given (or take them as
+        already centred, `centered=True`) and map the statistics back.
+        `ref_var` (D-vector): the image is relative to the reference Gaussian N(0, diag(ref_var)) of those
+        coordinates (skm_gmm_pack_ref): same posteriors and statistics from much smaller float32 partial sums;
+        estep adds the reference's log-likelihood back.  For estep / bw_stats only (loglik / logprob return
+        per-frame values)."""
         torch = self.torch
         w = _as_f64(w)
         mu = _as_f64(mu)
@@ -254,12 +261,23 @@ class HipEngine(object):
         if shift is not None:
             assert shift.D == D
             mu = mu - shift.host[None, :]
+        ref = None
+        if ref_var is not None:
+            ref = ref_var if isinstance(ref_var, FrameRef) else FrameRef(self, ref_var)
+            assert ref.D == D
         nbytes = self.lib.skm_gmm_packed_bytes(C, D)
         packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        self._check(self.lib.skm_gmm_pack(self.ctx, w.ctypes.data_as(_dp), mu.ctypes.data_as(_dp),
-                                          invcov.ctypes.data_as(_dp), C, D, _c_void_p(packed.data_ptr()),
-                                          self._stream()))
-        return PackedGMM(packed, C, D, shift)
+        self._check(self.lib.skm_gmm_pack_ref(self.ctx, w.ctypes.data_as(_dp), mu.ctypes.data_as(_dp),
+                                              invcov.ctypes.data_as(_dp),
+                                              ref.host.ctypes.data_as(_dp) if ref is not None else None, C, D,
+                                              _c_void_p(packed.data_ptr()), self._stream()))
+        return PackedGMM(packed, C, D, shift, ref)
+
+    def pack_stats(self, w, mu, invcov):
+        """pack() for the statistics kernels (estep / bw_stats) as the drop-in classes do it: frames centred when the
+        model sits far from the origin, image relative to the model's own reference Gaussian (stats_conditioning)."""
+        off, ref = stats_conditioning(w, mu, invcov)
+        return self.pack(w, mu, invcov, shift=off, ref_var=ref)
 
     def mstep_pack(self, stats, cov_var_ctl, gmm, ceil_cov, floor_cov, params=None, llk_mean=None):
         """M-step + re-pack on the device (skm_gmm_mstep_pack): `gmm` (a PackedGMM) is overwritten with the new
@@ -273,7 +291,8 @@ class HipEngine(object):
         self._check(self.lib.skm_gmm_mstep_pack(
             self.ctx, _c_void_p(stats.data_ptr()), _c_void_p(cov_var_ctl.data_ptr()), C, D, float(ceil_cov),
             float(floor_cov), _c_void_p(params.data_ptr()), _c_void_p(gmm.packed.data_ptr()),
-            _c_void_p(llk_mean.data_ptr()) if llk_mean is not None else None, self._stream()))
+            _c_void_p(llk_mean.data_ptr()) if llk_mean is not None else None,
+            _c_void_p(gmm.ref.dev.data_ptr()) if gmm.ref is not None else None, self._stream()))
         return params
 
     def estep(self, X, gmm, out=None, accumulate=False, centered=False, unshift=True):
@@ -286,19 +305,21 @@ class HipEngine(object):
         assert D == gmm.D and X.dtype == torch.float32 and X.is_contiguous()
         C = gmm.C
         n = 2 * C * D + C + 1
-        if gmm.shift is not None:
-            if not centered:
+        if gmm.shift is not None or gmm.ref is not None:
+            if gmm.shift is not None and not centered:
                 X = self.center_frames(X, gmm.shift)
-            if unshift:
-                part = self.estep(X, _unshifted(gmm), centered=True)
+            # the corrections are linear in the statistics of THIS call: they go on a fresh result, then it is added
+            fresh = out if (out is not None and not accumulate) else None
+            part = self.estep(X, _plain(gmm), out=fresh)
+            if gmm.ref is not None:
+                self._check(self.lib.skm_gmm_llk_ref(self.ctx, _c_void_p(part.data_ptr()), C, D, T,
+                                                     _c_void_p(gmm.ref.dev.data_ptr()), self._stream()))
+            if gmm.shift is not None and unshift:
                 self.stats_unshift_(part, C, D, gmm.shift)
-                if out is None or not accumulate:
-                    if out is None:
-                        return part
-                    out.copy_(part)
-                else:
-                    out += part
+            if out is not None and accumulate:
+                out += part
                 return out
+            return part
         if out is None:
             out = torch.empty(n, dtype=torch.float64, device=self.device)
             accumulate = False
@@ -326,6 +347,7 @@ class HipEngine(object):
         torch = self.torch
         T, D = X.shape
         assert D == gmm.D
+        assert gmm.ref is None, "per-frame log-likelihoods want an image packed without a reference Gaussian"
         if gmm.shift is not None and not centered:
             X = self.center_frames(X, gmm.shift)
         out = torch.empty(T, dtype=torch.float32, device=self.device)
@@ -341,6 +363,7 @@ class HipEngine(object):
         torch = self.torch
         T, D = X.shape
         assert D == gmm.D and X.dtype == torch.float32 and X.is_contiguous()
+        assert gmm.ref is None, "log-probabilities want an image packed without a reference Gaussian"
         if gmm.shift is not None and not centered and T > 0:
             X = self.center_frames(X, gmm.shift)
         lp = torch.empty((T, gmm.C), dtype=torch.float64, device=self.device)
@@ -408,7 +431,7 @@ class HipEngine(object):
         if gmm.shift is not None:
             if not centered and T > 0:
                 X = self.center_frames(X, gmm.shift, inplace=own_frames)
-            stat0, stat1 = self.bw_stats(X, seg_off, _unshifted(gmm), stat0, stat1, split_long)
+            stat0, stat1 = self.bw_stats(X, seg_off, _plain(gmm), stat0, stat1, split_long)
             self.bw_unshift_(stat0, stat1, D, gmm.shift)
             return stat0, stat1
         if split_long and not isinstance(seg_off, torch.Tensor):
@@ -963,18 +986,33 @@ class HipEngine(object):
 
 class PackedGMM(object):
     """Device image of a diagonal GMM in MFMA fragment order (see csrc/skm_gmm.hip).  `shift` (a FrameShift or
-    None): the image is the model of the frames minus that offset."""
+    None): the image is the model of the frames minus that offset.  `ref` (a FrameRef or None): the image is
+    relative to that reference Gaussian (skm_gmm_pack_ref)."""
 
-    def __init__(self, packed, C, D, shift=None):
+    def __init__(self, packed, C, D, shift=None, ref=None):
         self.packed = packed
         self.C = C
         self.D = D
         self.shift = shift
+        self.ref = ref
 
 
-def _unshifted(gmm):
-    """The same device image seen as a plain model (of the centred frames)."""
-    return PackedGMM(gmm.packed, gmm.C, gmm.D, None)
+def _plain(gmm):
+    """The same device image with no correction attached (what the kernels see)."""
+    return PackedGMM(gmm.packed, gmm.C, gmm.D, None, None)
+
+
+class FrameRef(object):
+    """Reference Gaussian N(0, diag(var)) of an image packed by skm_gmm_pack_ref: `host` / `dev` hold 1 / var
+    (0 where the variance is not a positive finite number: that dimension has no reference)."""
+
+    def __init__(self, engine, var):
+        var = np.asarray(var, dtype=np.float64).reshape(-1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = np.where(np.isfinite(var) & (var > 0), 1.0 / var, 0.0)
+        self.host = np.ascontiguousarray(np.where(np.isfinite(inv), inv, 0.0))
+        self.D = self.host.size
+        self.dev = engine.torch.from_numpy(self.host.copy()).to(engine.device)
 
 
 class FrameShift(object):
@@ -987,6 +1025,28 @@ class FrameShift(object):
         self.host = m32.astype(np.float64)
         self.D = self.host.size
         self.dev = engine.torch.from_numpy(self.host.copy()).to(engine.device)
+
+
+def stats_conditioning(w, mu, invcov):
+    """(offset or None, ref_var or None) that condition the float32 logits of a model for the statistics kernels
+    (both leave posteriors and statistics unchanged, include/skm.h):
+    offset   to centre the frames on when the model sits far from the origin (un-normalised features): the model's
+             own mean sum_c w_c mu_c, judged against its total standard deviation per dimension (centering_offset);
+    ref_var  per-dimension second moment of the whole model about that offset (float32-rounded, as the frames will
+             be shifted) -- the variance of the reference Gaussian of skm_gmm_pack_ref.  SKM_REF=0 switches it off."""
+    w = np.asarray(w, dtype=np.float64)
+    mu = np.asarray(mu, dtype=np.float64)
+    invcov = np.asarray(invcov, dtype=np.float64)
+    if mu.ndim != 2 or mu.size == 0:
+        return None, None
+    w = w / np.sum(w)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        m = w @ mu
+        second = w @ (1.0 / invcov + np.square(mu))
+    off = centering_offset(m, np.sqrt(np.maximum(second - np.square(m), 0.0)))
+    s = 0.0 if off is None else np.asarray(off, dtype=np.float32).astype(np.float64)
+    ref = None if os.environ.get("SKM_REF", "1") == "0" else second - 2.0 * s * m + np.square(s)
+    return off, ref
 
 
 def centering_offset(mean, std):

@@ -64,7 +64,7 @@ def gmm_scoring_singleThread(ubm, enroll, ndx, feature_server, score_mat, seg_id
     shift = ubm._auto_shift()
     if shift is not None:
         X = eng.center_frames(X, shift)
-    ubm_mean = eng.segment_mean(eng.loglik(X, ubm._pack(shift=shift), centered=True), seg_off_dev)
+    ubm_mean = eng.segment_mean(eng.loglik(X, ubm._pack(shift=shift, stats=False), centered=True), seg_off_dev)
 
     # models that take part in a trial of these segments AND are enrolled (gmm_scoring.py:87-93)
     mask = np.asarray(ndx.trialmask)[:, seg_idx]

@@ -293,7 +293,11 @@ class File(object):
         def cb(g, name, info, data):
             names.append(name.decode())
             return 0
-        fn = lib.H5Literate
+        # HDF5 1.12+ exports H5Literate1 / H5Literate2 (H5Literate is a macro there); the callback ignores the info
+        # argument, so either signature serves
+        fn = next((getattr(lib, n) for n in ("H5Literate1", "H5Literate", "H5Literate2") if hasattr(lib, n)), None)
+        if fn is None:
+            raise IOError("h5lite: this libhdf5 exports no H5Literate")
         fn.restype = ctypes.c_int
         fn.argtypes = [_hid, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_hsz), cb_t, ctypes.c_void_p]
         idx = _hsz(0)
@@ -325,13 +329,14 @@ class File(object):
         else:
             dims = (_hsz * a.ndim)(*a.shape)
             mx = None
-            filtered = a.size > 0 and (compression is not None or fletcher32 or maxshape is not None)
+            # a dataset that may grow is chunked even when it starts empty (a later resize needs the chunked layout)
+            filtered = maxshape is not None or (a.size > 0 and (compression is not None or fletcher32))
             if filtered:
                 if maxshape is not None:
                     mx = (_hsz * a.ndim)(*[H5S_UNLIMITED if m is None else int(m) for m in maxshape])
                 # chunks of about 1 MiB along the first dimension (whole rows)
                 row = max(1, int(np.prod(a.shape[1:], dtype=np.int64)) * a.dtype.itemsize)
-                c0 = int(max(1, min(a.shape[0], (1 << 20) // row)))
+                c0 = int(max(1, min(max(a.shape[0], 1), (1 << 20) // row)))
                 chunk = (_hsz * a.ndim)(c0, *[max(1, int(s)) for s in a.shape[1:]])
                 lib.H5Pset_chunk(dcpl, a.ndim, chunk)
                 # filter order as h5py's: checksum first, then deflate

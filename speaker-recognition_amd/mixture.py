@@ -215,24 +215,30 @@ class Mixture(object):
         self._compute_all()
 
     # ------------------------------------------------------------------ E-step on the GPU
-    def _auto_shift(self):
-        """Offset to centre the frames on when this model sits far from the origin (un-normalised features), else
-        None: the model's own mean sum_c w_c mu_c against its total standard deviation per dimension.  The kernels
-        accumulate logits in float32; centring keeps their magnitude at the spread of the model instead of its
-        distance from zero (engine.centering_offset, include/skm.h skm_frames_center)."""
-        if self.mu.ndim != 2 or self.mu.size == 0:
-            return None
-        w = self.w / np.sum(self.w)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            m = w @ self.mu
-            var = w @ (1.0 / self.invcov + np.square(self.mu)) - np.square(m)
-        off = _engine.centering_offset(m, np.sqrt(np.maximum(var, 0.0)))
-        return None if off is None else self.engine.frame_shift(off)
+    def _frame_model(self):
+        """(shift, ref_var) that condition the float32 logits of this model (the reference forms them in float64,
+        mixture.py:482-486; both leave posteriors and statistics unchanged, see include/skm.h):
+        shift    offset to centre the frames on when the model sits far from the origin (un-normalised features),
+                 else None: the model's own mean sum_c w_c mu_c against its total standard deviation per
+                 dimension (engine.centering_offset);
+        ref_var  per-dimension second moment of the whole model about that offset -- the variance of the
+                 reference Gaussian the statistics kernels' image is packed against (skm_gmm_pack_ref)."""
+        off, ref = _engine.stats_conditioning(self.w, self.mu, self.invcov)
+        return (None if off is None else self.engine.frame_shift(off)), ref
 
-    def _pack(self, shift="auto"):
-        if isinstance(shift, str):
-            shift = self._auto_shift()
-        return self.engine.pack(self.w, self.mu, self.invcov, shift=shift)
+    def _auto_shift(self):
+        return self._frame_model()[0]
+
+    def _pack(self, shift="auto", ref_var="auto", stats=True):
+        """Device image of this model.  stats=True: for the statistics kernels (E-step, Baum-Welch), packed against
+        the reference Gaussian; stats=False: for per-frame log-likelihoods / log-probabilities (plain)."""
+        if isinstance(shift, str) or (stats and isinstance(ref_var, str)):
+            auto_shift, auto_ref = self._frame_model()
+            if isinstance(shift, str):
+                shift = auto_shift
+            if isinstance(ref_var, str):
+                ref_var = auto_ref
+        return self.engine.pack(self.w, self.mu, self.invcov, shift=shift, ref_var=ref_var if stats else None)
 
     def _device_frames(self, cep):
         """float32 device view of `cep` (uploads a host array; device tensors pass through)."""
@@ -357,6 +363,8 @@ class Mixture(object):
         # it comes from the all-reduced moments)
         off = _engine.centering_offset(mu, np.sqrt(np.maximum(cov - np.square(mu), 0.0)))
         self._em_shift = None if off is None else self.engine.frame_shift(off)
+        sh = 0.0 if self._em_shift is None else self._em_shift.host
+        self._em_ref_var = _ref_var(cov - 2.0 * sh * mu + np.square(sh))   # E[(x - shift)^2] of all the frames
         return X_dev
 
     def EM_split(self,
@@ -376,7 +384,7 @@ class Mixture(object):
         commented out, mixture.py:711-731)."""
         llk = []
         X_dev = self._init(features_server, feature_list, num_thread)
-        shift = self._em_shift
+        shift, ref_var = self._em_shift, self._em_ref_var
         if shift is not None:
             X_dev = self.engine.center_frames(X_dev, shift)
         selected = False
@@ -399,15 +407,15 @@ class Mixture(object):
                         X_dev = self._resident_frames(features_server, feature_list)
                         if shift is not None:
                             X_dev = self.engine.center_frames(X_dev, shift)
-            llk.extend(self._em_iterations_device(X_dev, it, ceil_cov, floor_cov, shift=shift))
+            llk.extend(self._em_iterations_device(X_dev, it, ceil_cov, floor_cov, shift=shift, ref_var=ref_var))
         return llk
 
-    def _em_iterations_device(self, X_dev, it, ceil_cov=10, floor_cov=1e-2, shift=None):
+    def _em_iterations_device(self, X_dev, it, ceil_cov=10, floor_cov=1e-2, shift=None, ref_var="auto"):
         """`it` EM iterations of the loop body mixture.py:686-710 with the model resident on the GPU: E-step,
         all-reduce of the packed statistics, M-step + variance control + re-pack (skm_gmm_mstep_pack) -- no host
         round trip inside the loop.  The parameters and the per-iteration mean log-likelihoods come back once."""
         eng = self.engine
-        loop = _DeviceEM(self, X_dev, ceil_cov, floor_cov, shift=shift)
+        loop = _DeviceEM(self, X_dev, ceil_cov, floor_cov, shift=shift, ref_var=ref_var)
         llk_dev = eng.torch.empty(it, dtype=eng.torch.float64, device=eng.device)
         for i in range(it):
             loop.step(llk_mean=llk_dev[i:i + 1])
@@ -425,11 +433,11 @@ class Mixture(object):
             a, b = dist.shard_bounds(n_total)
             local = cep[a:b]
         X_dev = self._device_frames(local)
-        shift = self._auto_shift()          # from the initial model: the same on every rank
+        shift, ref_var = self._frame_model()          # from the initial model: the same on every rank
         if shift is not None:
             X_dev = self.engine.center_frames(X_dev, shift)
         # the model stays on the GPU; only the summed log-likelihood (8 bytes) is read per iteration for the gain test
-        loop = _DeviceEM(self, X_dev, 10, 1e-2, shift=shift)
+        loop = _DeviceEM(self, X_dev, 10, 1e-2, shift=shift, ref_var=ref_var)
         for i in range(0, iteration_max):
             stats = loop.step()
             llk.append(float(self.engine.to_host(stats[-1:])[0]) / n_total)
@@ -478,7 +486,7 @@ class Mixture(object):
         if cep.ndim == 1:
             cep = cep[None, :]
         if mu is None:
-            packed = self._pack()
+            packed = self._pack(stats=False)
         else:
             packed = self.engine.pack(self.w, np.asarray(mu, dtype=np.float64).reshape(self.mu.shape), self.invcov,
                                       shift=self._auto_shift())
@@ -490,7 +498,7 @@ class Mixture(object):
         """Per-frame log sum_c w_c N(x_t) on the GPU: the `log_lk` of sum_log_probabilities
         (statserver.py:83-95) without materialising the T x C matrix."""
         X = self._device_frames(cep)
-        return self.engine.to_host(self.engine.loglik(X, self._pack())).astype(np.float64)
+        return self.engine.to_host(self.engine.loglik(X, self._pack(stats=False))).astype(np.float64)
 
 
 
@@ -499,7 +507,7 @@ class _DeviceEM(object):
     rank's frames, all-reduce of the packed statistics, M-step + variance control + re-pack on the device
     (skm_gmm_mstep_pack); download() brings the parameters back and refreshes det / cst / A."""
 
-    def __init__(self, mixture, X_dev, ceil_cov, floor_cov, shift=None):
+    def __init__(self, mixture, X_dev, ceil_cov, floor_cov, shift=None, ref_var="auto"):
         """`shift`: X_dev holds frames centred on it (engine.center_frames); the loop then lives in the centred
         coordinates -- the M-step is translation invariant (mu' = F'/N, cov = S'/N - mu'^2, same w, same llk) -- and
         download() moves the means back."""
@@ -507,7 +515,7 @@ class _DeviceEM(object):
         self.m, self.eng, self.X = mixture, eng, X_dev
         self.ceil, self.floor = ceil_cov, floor_cov
         self.shift = shift
-        self.packed = mixture._pack(shift=shift)
+        self.packed = mixture._pack(shift=shift, ref_var=ref_var)
         self.ctl = eng.torch.from_numpy(np.ascontiguousarray(mixture.cov_var_ctl, dtype=np.float64)).to(eng.device)
         self.params = self.stats = None
 
@@ -531,6 +539,13 @@ class _DeviceEM(object):
             m.mu += self.shift.host[None, :]
         m.invcov = flat[C + C * D:C + 2 * C * D].reshape(C, D).copy()
         m._compute_all()
+
+
+def _ref_var(second_moment):
+    """Variance vector of the reference Gaussian, or None when SKM_REF=0 switches the reference packing off (A/B)."""
+    if os.environ.get("SKM_REF", "1") == "0":
+        return None
+    return np.asarray(second_moment, dtype=np.float64)
 
 
 def _h5():

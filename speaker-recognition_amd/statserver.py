@@ -110,6 +110,11 @@ class StatServer(object):
                           for v in self.start], dtype=np.int64)
         stop = np.array([-1 if (v is None or (isinstance(v, float) and np.isnan(v))) else int(v)
                          for v in self.stop], dtype=np.int64)
+        # The reference stores both as int8 (statserver.py:420,424), which wraps frame indices above 127.  Same
+        # type whenever it holds the values (always for the all-None start / stop of the experiment scripts), the
+        # IdMap file's int32 (bosaris/idmap.py:104,108) otherwise: readers only compare with -1.
+        fits = all(a.size == 0 or (a.min() >= -128 and a.max() <= 127) for a in (start, stop))
+        start, stop = (a.astype(np.int8 if fits else np.int32) for a in (start, stop))
         data = {prefix + "modelset": np.asarray(self.modelset).astype('S'),
                 prefix + "segset": np.asarray(self.segset).astype('S'),
                 prefix + "stat0": self.stat0.astype(np.float32),
@@ -261,11 +266,27 @@ class StatServer(object):
                 self.stat0[rows, :] = eng.to_host(s0)
                 self.stat1[rows, :] = eng.to_host(s1)
 
-        def finish_stores():
-            while pending:
-                pending.pop(0).result()                     # re-raises what the worker raised
-            if pipelined:
-                pool.shutdown()
+        def finish_stores(abort=False):
+            """Waits for the drain jobs (re-raising what a worker raised) and stops the worker thread.  `abort`: the
+            main loop failed -- jobs that have not started are cancelled, the running one is awaited so that nothing
+            writes into stat0 / stat1 after this method has returned, and their own errors are dropped in favour
+            of the one being raised."""
+            try:
+                while pending:
+                    job = pending.pop(0)
+                    if abort:
+                        job.cancel()
+                        try:
+                            job.result()
+                        except BaseException:
+                            pass
+                    else:
+                        job.result()
+            finally:
+                if pipelined:
+                    for job in pending:
+                        job.cancel()
+                    pool.shutdown(wait=True)
 
         batch, batch_idx, nframes = [], [], 0
 
@@ -288,47 +309,51 @@ class StatServer(object):
                 channel = 1
             return show[:show.rfind(channel_extension[channel])], channel
 
-        # Device data plane: a features server that post-processes on the GPU (skm_feat_postproc) hands over
-        # whole batches of sessions already VAD-selected in HBM -- same result as load() + cep[vad]
-        # (statserver.py:645-652: statistics over the labelled frames of the fully normalised session).
-        if getattr(feature_server, "has_post_processing", lambda: False)() and hasattr(feature_server, "load_batch") \
-                and all(self.start[i] is None and self.stop[i] is None for i in mine):
-            todo = list(mine)
-            while todo:
-                take, nfr = [], 0
-                while todo and (not take or nfr < max_batch_frames):
-                    i = todo.pop(0)
-                    take.append(i)
-                    nfr += feature_server.features[show_of(i)[0]].shape[0]
-                X, seg_off, _ = feature_server.load_batch([show_of(i)[0] for i in take], keep_all_features=False)
-                if not ubm.dim() == X.shape[1]:
-                    raise Exception('dimension of ubm and features differ: {:d} / {:d}'.format(ubm.dim(), X.shape[1]))
-                s0, s1 = eng.bw_stats(X, seg_off, packed)
-                store(take, s0, s1)
-            mine_loop = []
-        else:
-            mine_loop = mine
+        try:
+            # Device data plane: a features server that post-processes on the GPU (skm_feat_postproc) hands over
+            # whole batches of sessions already VAD-selected in HBM -- same result as load() + cep[vad]
+            # (statserver.py:645-652: statistics over the labelled frames of the fully normalised session).
+            if getattr(feature_server, "has_post_processing", lambda: False)() and hasattr(feature_server, "load_batch") \
+                    and all(self.start[i] is None and self.stop[i] is None for i in mine):
+                todo = list(mine)
+                while todo:
+                    take, nfr = [], 0
+                    while todo and (not take or nfr < max_batch_frames):
+                        i = todo.pop(0)
+                        take.append(i)
+                        nfr += feature_server.features[show_of(i)[0]].shape[0]
+                    X, seg_off, _ = feature_server.load_batch([show_of(i)[0] for i in take], keep_all_features=False)
+                    if not ubm.dim() == X.shape[1]:
+                        raise Exception('dimension of ubm and features differ: {:d} / {:d}'.format(ubm.dim(), X.shape[1]))
+                    s0, s1 = eng.bw_stats(X, seg_off, packed)
+                    store(take, s0, s1)
+                mine_loop = []
+            else:
+                mine_loop = mine
 
-        for idx in mine_loop:
-            show, channel = show_of(idx)
-            cep, vad = feature_server.load(show, channel=channel,
-                                           input_feature_filename=feature_server.feature_filename_structure)
-            if type(cep).__module__.startswith("torch"):
-                cep = cep.detach().cpu().numpy()
-            stop = vad.shape[0] if self.stop[idx] is None else min(self.stop[idx], vad.shape[0])
-            data = cep[self.start[idx]:stop, :]
-            sel = vad[self.start[idx]:stop]
-            if not sel.all():               # the reference's data[vad] copies even when every frame is kept
-                data = data[sel, :]
-            if not ubm.dim() == data.shape[1]:
-                raise Exception('dimension of ubm and features differ: {:d} / {:d}'.format(ubm.dim(), data.shape[1]))
-            batch.append(np.asarray(data, dtype=np.float32))
-            batch_idx.append(idx)
-            nframes += data.shape[0]
-            if nframes >= (min(max_batch_frames, 1 << 20) if pipelined else max_batch_frames):
-                run_batch()             # pipelined: batches of about a million frames keep all three stages busy
-                batch, batch_idx, nframes = [], [], 0
-        run_batch()
+            for idx in mine_loop:
+                show, channel = show_of(idx)
+                cep, vad = feature_server.load(show, channel=channel,
+                                               input_feature_filename=feature_server.feature_filename_structure)
+                if type(cep).__module__.startswith("torch"):
+                    cep = cep.detach().cpu().numpy()
+                stop = vad.shape[0] if self.stop[idx] is None else min(self.stop[idx], vad.shape[0])
+                data = cep[self.start[idx]:stop, :]
+                sel = vad[self.start[idx]:stop]
+                if not sel.all():               # the reference's data[vad] copies even when every frame is kept
+                    data = data[sel, :]
+                if not ubm.dim() == data.shape[1]:
+                    raise Exception('dimension of ubm and features differ: {:d} / {:d}'.format(ubm.dim(), data.shape[1]))
+                batch.append(np.asarray(data, dtype=np.float32))
+                batch_idx.append(idx)
+                nframes += data.shape[0]
+                if nframes >= (min(max_batch_frames, 1 << 20) if pipelined else max_batch_frames):
+                    run_batch()             # pipelined: batches of about a million frames keep all three stages busy
+                    batch, batch_idx, nframes = [], [], 0
+            run_batch()
+        except BaseException:
+            finish_stores(abort=True)
+            raise
         finish_stores()
 
         if keep_on_device and kept:

@@ -14,6 +14,7 @@ class _Packed(object):
         self.gmm = orc.GMM(w, mu, invcov)
         self.C, self.D = self.gmm.C, self.gmm.D
         self.shift = shift
+        self.ref = None         # the float64 oracle needs no reference Gaussian (a float32 conditioning device)
 
 
 class _Shift(object):
@@ -55,7 +56,7 @@ class OracleEngine(object):
         a[C + C * D:C + 2 * C * D] += (m * (2.0 * F + N[:, None] * m)).ravel()
         return flat
 
-    def pack(self, w, mu, invcov, shift=None):
+    def pack(self, w, mu, invcov, shift=None, ref_var=None):
         shift = self.frame_shift(shift)
         mu = np.asarray(mu, dtype=np.float64)
         return _Packed(w, mu if shift is None else mu - shift.host[None, :], invcov, shift)

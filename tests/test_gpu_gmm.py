@@ -35,7 +35,7 @@ def unpack(flat, C, D):
 
 def run_estep(eng, gmm, cep):
     X = eng.upload_frames(cep)
-    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    packed = eng.pack_stats(gmm.w, gmm.mu, gmm.invcov)
     return unpack(eng.to_host(eng.estep(X, packed)), gmm.C, gmm.D)
 
 
@@ -100,7 +100,7 @@ def test_estep_vs_oracle_shapes(eng, C, D, T):
 def test_estep_accumulate_and_empty(eng):
     gmm = orc.random_gmm(16, 12, seed=1)
     cep = orc.synth_frames(3000, dim=12, clusters=8, seed=2)
-    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    packed = eng.pack_stats(gmm.w, gmm.mu, gmm.invcov)
     full = eng.to_host(eng.estep(eng.upload_frames(cep), packed))
     out = eng.estep(eng.upload_frames(cep[:1111]), packed)
     out = eng.estep(eng.upload_frames(cep[1111:]), packed, out=out, accumulate=True)
@@ -136,7 +136,7 @@ def test_bw_stats_vs_reference_golden(eng):
     g = golden("accumulate_stat.npz")
     gmm = orc.GMM(g["w"], g["mu"], g["invcov"])
     sess, off = _sessions(g)
-    s0, s1 = eng.bw_stats(eng.upload_frames(g["frames"]), off, eng.pack(gmm.w, gmm.mu, gmm.invcov))
+    s0, s1 = eng.bw_stats(eng.upload_frames(g["frames"]), off, eng.pack_stats(gmm.w, gmm.mu, gmm.invcov))
     s0, s1 = eng.to_host(s0), eng.to_host(s1)
     assert rel(s0, g["stat0"]) < TOL
     assert rel(s1, g["stat1"]) < TOL
@@ -154,7 +154,7 @@ def test_bw_stats_ragged_and_empty_sessions(eng):
     lens = [0, 1, 31, 32, 33, 0, 500, 64, 1]
     frames = orc.synth_frames(sum(lens), dim=D, seed=6)
     off = np.concatenate([[0], np.cumsum(lens)])
-    s0, s1 = eng.bw_stats(eng.upload_frames(frames), off, eng.pack(gmm.w, gmm.mu, gmm.invcov))
+    s0, s1 = eng.bw_stats(eng.upload_frames(frames), off, eng.pack_stats(gmm.w, gmm.mu, gmm.invcov))
     s0, s1 = eng.to_host(s0), eng.to_host(s1)
     r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
     assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
@@ -175,7 +175,7 @@ def test_bw_stats_team_kernel_ragged_and_empty_sessions(eng, C, D):
     frames = orc.synth_frames(sum(lens), dim=D, seed=10)
     off = np.concatenate([[0], np.cumsum(lens)])
     X = eng.upload_frames(frames)
-    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    packed = eng.pack_stats(gmm.w, gmm.mu, gmm.invcov)
     s0, s1 = eng.bw_stats(X, off, packed)
     s0, s1 = eng.to_host(s0), eng.to_host(s1)
     r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
@@ -211,7 +211,7 @@ def test_bw_stats_small_blocks_and_wide_rows(eng, C, D):
     frames = orc.synth_frames(sum(lens), dim=D, seed=10)
     off = np.concatenate([[0], np.cumsum(lens)])
     X = eng.upload_frames(frames)
-    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    packed = eng.pack_stats(gmm.w, gmm.mu, gmm.invcov)
     s0, s1 = eng.bw_stats(X, off, packed)
     s0, s1 = eng.to_host(s0), eng.to_host(s1)
     r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
@@ -255,7 +255,7 @@ def test_posteriors_of_a_frame_sum_to_one(eng, C, D):
     gmm = orc.random_gmm(C, D, seed=C + D)
     frames = orc.synth_frames(int(off[-1]), dim=D, seed=12)
     X = eng.upload_frames(frames)
-    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    packed = eng.pack_stats(gmm.w, gmm.mu, gmm.invcov)
     s0, _ = eng.bw_stats(X, off, packed)
     s0 = eng.to_host(s0)
     defect = np.abs(s0.sum(1) - lens) / lens
@@ -282,7 +282,7 @@ def test_bw_stats_few_long_sessions_are_split(eng, C, D):
     for k, s in enumerate(owner):                                  # every piece lies inside its session, 32-aligned start
         assert off[s] <= pieces[k] and pieces[k + 1] <= off[s + 1] and (pieces[k] - off[s]) % 32 == 0
     X = eng.upload_frames(frames)
-    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    packed = eng.pack_stats(gmm.w, gmm.mu, gmm.invcov)
     s0, s1 = eng.bw_stats(X, off, packed)
     u0, u1 = eng.bw_stats(X, off, packed, split_long=False)
     s0, s1, u0, u1 = eng.to_host(s0), eng.to_host(s1), eng.to_host(u0), eng.to_host(u1)
@@ -338,7 +338,7 @@ def test_statserver_accumulate_stat_pipelined_batches(sk, eng):
     ss.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(S), num_thread=1)
     assert ss.stat0.shape == (S, C) and ss.stat1.shape == (S, C * D)
     assert np.abs(ss.stat0.sum(1) - lens).max() / lens.max() < 1e-5
-    t0, t1 = eng.bw_stats(eng.upload_frames(frames), off, eng.pack(gmm.w, gmm.mu, gmm.invcov))
+    t0, t1 = eng.bw_stats(eng.upload_frames(frames), off, eng.pack_stats(gmm.w, gmm.mu, gmm.invcov))
     t0, t1 = eng.to_host(t0), eng.to_host(t1)
     for i in range(S):      # row by row: a row that landed in the wrong place or was never written shows here
         assert np.abs(ss.stat0[i] - t0[i]).max() <= 5e-5 * max(np.abs(t0[i]).max(), 1e-30), i

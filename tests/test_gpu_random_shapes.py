@@ -41,7 +41,7 @@ def test_random_shape_vs_oracle(eng, seed):
     gmm = orc.random_gmm(C, D, seed=seed)
     frames = orc.synth_frames(T, dim=D, clusters=8, seed=100 + seed)
     X = eng.upload_frames(frames)
-    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov)
+    packed = eng.pack_stats(gmm.w, gmm.mu, gmm.invcov)      # as the drop-in classes pack for E-step / Baum-Welch
     what = "seed %d: C=%d D=%d T=%d sessions=%d" % (seed, C, D, T, ns)
 
     flat = eng.to_host(eng.estep(X, packed))
@@ -53,7 +53,7 @@ def test_random_shape_vs_oracle(eng, seed):
     assert max(rows) < TOL, (what, rows)
     assert abs(llk - rsum) <= 1e-6 * abs(rsum), what
     rllk = orc.logsumexp_rows(orc.log_posterior(gmm, x64))[1]
-    assert rel(eng.to_host(eng.loglik(X, packed)), rllk) < 1e-5, what
+    assert rel(eng.to_host(eng.loglik(X, eng.pack(gmm.w, gmm.mu, gmm.invcov))), rllk) < 1e-5, what
 
     s0, s1 = eng.bw_stats(X, off, packed)
     s0, s1 = eng.to_host(s0), eng.to_host(s1)

@@ -105,8 +105,8 @@ def test_centred_c_abi_vs_oracle_shapes(eng, C, D, T):
     gmm = orc.raw_gmm(C, D, seed=C + D)
     cep = orc.synth_raw_frames(T, dim=D, clusters=16, seed=T)
     x64 = cep.astype(np.float64)
-    shift = eng.frame_shift(gmm.w @ gmm.mu)
-    packed = eng.pack(gmm.w, gmm.mu, gmm.invcov, shift=shift)
+    packed = eng.pack_stats(gmm.w, gmm.mu, gmm.invcov)
+    assert packed.shift is not None and packed.ref is not None
     X = eng.upload_frames(cep)
     flat = eng.to_host(eng.estep(X, packed))
     N, F, S, llk = flat[:C], flat[C:C + C * D].reshape(C, D), flat[C + C * D:C + 2 * C * D].reshape(C, D), flat[-1]
@@ -127,7 +127,7 @@ def test_centred_c_abi_vs_oracle_shapes(eng, C, D, T):
     r0, r1 = orc.accumulate_stat(gmm, [x64[off[i]:off[i + 1]] for i in range(len(off) - 1)])
     assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
     assert rel_rows(s0, r0) < TOL and rel_rows(s1, r1) < TOL
-    ll = eng.to_host(eng.loglik(X, packed)).astype(np.float64)
+    ll = eng.to_host(eng.loglik(X, eng.pack(gmm.w, gmm.mu, gmm.invcov, shift=packed.shift))).astype(np.float64)
     rll = orc.logsumexp_rows(orc.log_posterior(gmm, x64))[1]
     assert np.abs(ll - rll).max() < 1e-5 * np.abs(rll).max()
 

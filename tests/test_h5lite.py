@@ -257,3 +257,137 @@ def test_key_files_and_score_split(tmp_path, ext):
     sc.scoremat = np.array([[3.0, 2.0, -1.0], [-2.0, 9.0, 4.0]])
     tar, non = sc.get_tar_non(key)
     assert sorted(tar) == [2.0, 3.0, 4.0] and sorted(non) == [-2.0, -1.0]
+
+
+# ---- layout of the file products, checked by an INDEPENDENT reader: the HDF5 command-line tool h5dump ----
+def _h5dump():
+    import shutil
+    for c in (os.environ.get("SKM_H5DUMP"), shutil.which("h5dump"), "/opt/conda/bin/h5dump", "/usr/bin/h5dump"):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def _header(fn):
+    """{dataset path: text of its h5dump -H -p block}"""
+    import re
+    import subprocess
+    tool = _h5dump()
+    if tool is None:
+        pytest.skip("h5dump not found")
+    txt = subprocess.run([tool, "-H", "-p", fn], check=True, capture_output=True, text=True).stdout
+    out, stack, cur = {}, [], None
+    for line in txt.splitlines():
+        m = re.match(r'\s*(GROUP|DATASET) "([^"]+)" \{', line)
+        if m:
+            stack.append((m.group(1), m.group(2), line.count("{") - line.count("}")))
+            if m.group(1) == "DATASET":
+                cur = "/".join(n for k, n, _ in stack if n != "/")
+                out[cur] = ""
+            continue
+        if cur is not None:
+            out[cur] += line + "\n"
+        if stack:
+            k, n, depth = stack[-1]
+            depth += line.count("{") - line.count("}")
+            stack[-1] = (k, n, depth)
+            if depth <= 0:
+                if k == "DATASET":
+                    cur = None
+                stack.pop()
+    return out
+
+
+def _expect(block, dtype, dims, maxdims, filtered=True):
+    import re
+    assert dtype in block, (dtype, block)
+    m = re.search(r"DATASPACE\s+SIMPLE \{ \(([^)]*)\) / \(([^)]*)\) \}", block)
+    assert m, block
+    assert [s.strip() for s in m.group(1).split(",")] == [str(d) for d in dims], block
+    assert [s.strip() for s in m.group(2).split(",")] == [str(d) for d in maxdims], block
+    if filtered:
+        assert "CHUNKED" in block and "CHECKSUM FLETCHER32" in block and "COMPRESSION DEFLATE { LEVEL 4 }" in block, block
+
+
+def test_layout_of_file_products_as_h5dump_sees_them(tmp_path):
+    """What the reference's own h5py calls produce (statserver.py:426-455, mixture.py:332-358,
+    factor_analyser.py:270-296, bosaris/idmap.py:90-115): dataset names, storage types, extents and maximum extents,
+    gzip level 4 (h5py's default) + fletcher32 on chunked datasets -- read back by the HDF5 tools, not by h5lite."""
+    rs = np.random.RandomState(5)
+    C, D, S, R = 4, 3, 6, 2
+    # StatServer
+    ss = sk.StatServer()
+    ss.modelset = np.array(["spk%d" % (i % 2) for i in range(S)])
+    ss.segset = np.array(["seg-%03d" % i for i in range(S)])
+    ss.start = np.empty(S, "|O")
+    ss.stop = np.empty(S, "|O")
+    ss.stat0 = rs.rand(S, C)
+    ss.stat1 = rs.randn(S, C * D)
+    fn = str(tmp_path / "stat.h5")
+    ss.write(fn)
+    h = _header(fn)
+    assert sorted(h) == ["modelset", "segset", "start", "stat0", "stat1", "stop"]
+    _expect(h["stat0"], "H5T_IEEE_F32LE", (S, C), ("H5S_UNLIMITED", C))
+    _expect(h["stat1"], "H5T_IEEE_F32LE", (S, C * D), ("H5S_UNLIMITED", C * D))
+    for k in ("modelset", "segset"):
+        _expect(h[k], "H5T_STRING", (S,), ("H5S_UNLIMITED",))
+        assert "STRPAD H5T_STR_NULLPAD" in h[k] and "CSET H5T_CSET_ASCII" in h[k]
+    assert "STRSIZE 4;" in h["modelset"] and "STRSIZE 7;" in h["segset"]
+    for k in ("start", "stop"):                      # all None -> -1 in the reference's int8 (statserver.py:418-424)
+        _expect(h[k], "H5T_STD_I8LE", (S,), ("H5S_UNLIMITED",))
+    ss.start[:] = 300                                # beyond int8: widened instead of wrapped
+    ss.stop[:] = 900
+    ss.write(fn)
+    _expect(_header(fn)["start"], "H5T_STD_I32LE", (S,), ("H5S_UNLIMITED",))
+    # Mixture
+    m = sk.Mixture()
+    m.w = np.full(C, 1.0 / C)
+    m.mu = rs.randn(C, D)
+    m.invcov = rs.uniform(0.5, 2.0, (C, D))
+    m.cov_var_ctl = 1.0 / m.invcov
+    m._compute_all()
+    fn = str(tmp_path / "ubm.h5")
+    m.write(fn)
+    h = _header(fn)
+    assert sorted(h) == sorted(["w", "mu", "invcov", "invchol", "cov_var_ctl", "cst", "det", "a"])
+    _expect(h["w"], "H5T_IEEE_F64LE", (C,), (C,))
+    _expect(h["mu"], "H5T_IEEE_F64LE", (C, D), (C, D))
+    _expect(h["invcov"], "H5T_IEEE_F64LE", (C, D), (C, D))
+    _expect(h["a"], "H5T_IEEE_F64LE", (C,), (C,))
+    # FactorAnalyser
+    fa = sk.FactorAnalyser()
+    fa.mean = rs.randn(C * D)
+    fa.F = rs.randn(C * D, R)
+    fa.Sigma = rs.rand(C * D)
+    fn = str(tmp_path / "tv.h5")
+    fa.write(fn)
+    h = _header(fn)
+    assert sorted(h) == ["fa/f", "fa/kind", "fa/mean", "fa/sigma"]
+    _expect(h["fa/f"], "H5T_IEEE_F64LE", (C * D, R), (C * D, R))
+    _expect(h["fa/kind"], "H5T_STD_I16LE", (5,), (5,))
+    # IdMap
+    im = sk.IdMap()
+    im.leftids = ss.modelset
+    im.rightids = ss.segset
+    im.start = np.empty(S, "|O")
+    im.stop = np.empty(S, "|O")
+    fn = str(tmp_path / "idmap.h5")
+    im.write(fn)
+    h = _header(fn)
+    assert sorted(h) == ["leftids", "rightids", "start", "stop"]
+    _expect(h["leftids"], "H5T_STRING", (S,), ("H5S_UNLIMITED",))
+    _expect(h["start"], "H5T_STD_I32LE", (S,), ("H5S_UNLIMITED",))
+    _expect(h["stop"], "H5T_STD_I32LE", (S,), ("H5S_UNLIMITED",))
+
+
+def test_growing_a_file_that_started_empty(tmp_path):
+    """create_dataset(maxshape=...) on zero rows must still be chunked, or StatServer.write(mode='a') cannot resize."""
+    fn = str(tmp_path / "grow.h5")
+    with h5lite.File(fn, "w") as f:
+        f.create_dataset("x", data=np.zeros((0, 3), dtype=np.float32), maxshape=(None, 3), compression="gzip",
+                         fletcher32=True)
+    with h5lite.File(fn, "a") as f:
+        f["x"].resize((2, 3))
+        f["x"][0:] = np.arange(6, dtype=np.float32).reshape(2, 3)
+    with h5lite.File(fn, "r") as f:
+        np.testing.assert_array_equal(f["x"][()], np.arange(6, dtype=np.float32).reshape(2, 3))
