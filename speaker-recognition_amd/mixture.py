@@ -332,9 +332,9 @@ class Mixture(object):
         feats = features_server.stack_features_parallel(feature_list[first:last], num_thread=1)
         return self._device_frames(feats[a - int(off[first]):max(b, a) - int(off[first])] if b > a else feats[:0])
 
-    def _global_stats(self, X_dev):
+    def _global_stats(self, X_dev, packed=None):
         """E-step on the local shard + all-reduce -> host (N, F, S, llk)."""
-        out = self._estep_device(X_dev)
+        out = self._estep_device(X_dev, packed)
         dist.allreduce_sum_(out)
         return self._unpack_stats(self.engine.to_host(out))
 

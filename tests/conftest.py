@@ -41,17 +41,43 @@ def rel_large(a, b, frac=0.05):
     return (np.abs(a - b)[m] / np.abs(b)[m]).max() if m.any() else 0.0
 
 
-def rel_rows(a, b, frac=0.05, floor=1e-25):
-    """worst ELEMENT-WISE relative error over the entries that carry their ROW: |ref| >= frac * max |ref| of the row
-    (a component's row of F / S, a session's row of stat0 / stat1, one i-vector).  A 1-D array is one row per entry
-    (frac has no effect: every non-negligible entry is judged).  Rows whose largest entry is below `floor` times the
-    largest entry of the array are skipped: float32 products of posteriors that small are denormal."""
+def _rows(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
-    if a.ndim == 1:
-        a, b = a[:, None], b[:, None]
-    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    if a.ndim == 1:                 # a vector (N, w, one session) is ONE row
+        a, b = a[None, :], b[None, :]
+    return a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+
+
+def rel_rows(a, b, frac=0.05, floor=1e-25):
+    """worst ELEMENT-WISE relative error over the entries that carry their ROW: |ref| >= frac * max |ref| of the row
+    (a component's row of F / S, a session's row of stat0 / stat1, one i-vector; a 1-D array is one row).  Rows whose
+    largest entry is below `floor` times the largest entry of the array are skipped: float32 products of posteriors
+    that small are denormal."""
+    a, b = _rows(a, b)
     rmax = np.abs(b).max(axis=1, keepdims=True)
     m = (np.abs(b) >= frac * rmax) & (rmax > floor * max(np.abs(b).max(), 1e-300)) & (np.abs(b) > 0)
     return (np.abs(a - b)[m] / np.abs(b)[m]).max() if m.any() else 0.0
+
+
+def rel_rownorm(a, b, floor=1e-25):
+    """worst ROW-normwise error: max over rows of (max |delta| of the row / max |ref| of the row) -- every row is judged
+    on its own scale, a row 100 times below the largest one cannot hide."""
+    a, b = _rows(a, b)
+    rmax = np.abs(b).max(axis=1)
+    keep = rmax > floor * max(np.abs(b).max(), 1e-300)
+    return (np.abs(a - b).max(axis=1)[keep] / rmax[keep]).max() if keep.any() else 0.0
+
+
+# First-order statistics are sums of terms of both signs: F[c, d] = sum_t gamma[t, c] x[t, d].  An error of relative size
+# eps in the posteriors (float32 logits: eps ~ 1e-5 at 60 columns, the reference's float64 logits: 1e-16) moves F[c, d] by up
+# to eps * sum_t gamma |x|, which an entry at 5 % of its row's maximum sees 20 times enlarged.  F rows therefore carry three
+# measures: row-normwise at 1e-4, element-wise against the sum of magnitudes at 1e-4 (where the test has the posteriors),
+# and the plain element-wise ratio on the entries >= 5 % of their row's maximum at CANCEL_TOL.
+CANCEL_TOL = 1e-3
+
+
+def check_first_order(F, rF, tol=1e-4, what=""):
+    assert rel_rownorm(F, rF) < tol, (what, "row-normwise", rel_rownorm(F, rF))
+    assert rel_rows(F, rF) < CANCEL_TOL, (what, "element-wise on entries >= 5 % of their row", rel_rows(F, rF))

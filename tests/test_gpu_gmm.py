@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import sidekit_ref as orc
-from conftest import golden, rel, rel_large, rel_rows
+from conftest import golden, rel, rel_large, rel_rows, rel_rownorm, check_first_order
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +51,8 @@ def test_estep_vs_reference_golden(eng, tag):
     assert rel_large(F, g["F"]) < TOL
     assert rel_large(S, g["S"]) < TOL
     # element-wise on the entries that carry their component's row (every N_c; F_c and S_c per component)
-    assert rel_rows(N, g["N"]) < TOL and rel_rows(F, g["F"]) < TOL and rel_rows(S, g["S"]) < TOL
+    assert rel_rows(N, g["N"]) < TOL and rel_rows(S, g["S"]) < TOL and rel_rownorm(S, g["S"]) < TOL
+    check_first_order(F, g["F"])
     assert abs(llk - float(g["llk"])) < 1e-5 * abs(float(g["llk"]))
     # M-step from the device statistics reproduces the reference's next model
     orc.maximization(gmm, N, F, S)
@@ -91,8 +92,9 @@ def test_estep_vs_oracle_shapes(eng, C, D, T):
     assert rel(F, rF) < TOL
     assert rel(S, rS) < TOL
     # north star: "within 1e-4 relative" -- element-wise on the entries that carry their component's row
-    rows = (rel_rows(N, rN), rel_rows(F, rF), rel_rows(S, rS))
+    rows = (rel_rows(N, rN), rel_rows(S, rS), rel_rownorm(S, rS))
     assert max(rows) < TOL, rows
+    check_first_order(F, rF)
     assert abs(llk - rl) < 1e-5 * abs(rl)
     assert abs(N.sum() - T) < 1e-4 * T          # posteriors sum to one per frame
 
@@ -141,7 +143,8 @@ def test_bw_stats_vs_reference_golden(eng):
     assert rel(s0, g["stat0"]) < TOL
     assert rel(s1, g["stat1"]) < TOL
     assert rel_large(s0, g["stat0"]) < TOL and rel_large(s1, g["stat1"]) < TOL     # element-wise on the entries that matter
-    assert rel_rows(s0, g["stat0"]) < TOL and rel_rows(s1, g["stat1"]) < TOL       # ... of every session's row
+    assert rel_rows(s0, g["stat0"]) < TOL                                           # ... of every session's row
+    check_first_order(s1, g["stat1"])
     # per-session normwise too (short sessions must be as accurate as long ones)
     for i in range(len(sess)):
         assert rel(s0[i], g["stat0"][i]) < TOL
@@ -158,7 +161,8 @@ def test_bw_stats_ragged_and_empty_sessions(eng):
     s0, s1 = eng.to_host(s0), eng.to_host(s1)
     r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
     assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
-    assert rel_rows(s0, r0) < TOL and rel_rows(s1, r1) < TOL, (rel_rows(s0, r0), rel_rows(s1, r1))
+    assert rel_rows(s0, r0) < TOL and rel_rownorm(s1, r1) < TOL, (rel_rows(s0, r0), rel_rownorm(s1, r1))
+    check_first_order(s1, r1)
     assert np.all(s0[0] == 0) and np.all(s1[5] == 0)
     assert np.allclose(s0.sum(1), lens, rtol=1e-4)
 
@@ -180,7 +184,8 @@ def test_bw_stats_team_kernel_ragged_and_empty_sessions(eng, C, D):
     s0, s1 = eng.to_host(s0), eng.to_host(s1)
     r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
     assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
-    assert rel_rows(s0, r0) < TOL and rel_rows(s1, r1) < TOL, (rel_rows(s0, r0), rel_rows(s1, r1))
+    assert rel_rows(s0, r0) < TOL and rel_rownorm(s1, r1) < TOL, (rel_rows(s0, r0), rel_rownorm(s1, r1))
+    check_first_order(s1, r1)
     for i, n in enumerate(lens):
         if n == 0:
             assert np.all(s0[i] == 0) and np.all(s1[i] == 0)
@@ -216,7 +221,8 @@ def test_bw_stats_small_blocks_and_wide_rows(eng, C, D):
     s0, s1 = eng.to_host(s0), eng.to_host(s1)
     r0, r1 = orc.accumulate_stat(gmm, [frames[off[i]:off[i + 1]].astype(np.float64) for i in range(len(lens))])
     assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
-    assert rel_rows(s0, r0) < TOL and rel_rows(s1, r1) < TOL, (rel_rows(s0, r0), rel_rows(s1, r1))
+    assert rel_rows(s0, r0) < TOL and rel_rownorm(s1, r1) < TOL, (rel_rows(s0, r0), rel_rownorm(s1, r1))
+    check_first_order(s1, r1)
     for i, n in enumerate(lens):
         if n == 0:
             assert np.all(s0[i] == 0) and np.all(s1[i] == 0)
@@ -309,7 +315,8 @@ def test_statserver_accumulate_stat_dropin(sk):
     assert ss.validate()
     assert rel(ss.stat0, g["stat0"]) < TOL
     assert rel(ss.stat1, g["stat1"]) < TOL
-    assert rel_rows(ss.stat0, g["stat0"]) < TOL and rel_rows(ss.stat1, g["stat1"]) < TOL
+    assert rel_rows(ss.stat0, g["stat0"]) < TOL
+    check_first_order(ss.stat1, g["stat1"])
     with pytest.raises(Exception):
         bad = sk.FeaturesServer(features={n: np.zeros((5, ubm.dim() + 1)) for n in names})
         ss.accumulate_stat(ubm=ubm, feature_server=bad, seg_indices=range(2))
@@ -360,8 +367,8 @@ def test_em_split_dropin_vs_reference_golden(sk):
     assert rel(ubm.mu, g["mu"]) < TOL
     assert rel(1.0 / ubm.invcov, 1.0 / g["invcov"]) < TOL
     # UBM w / mu / covariance element-wise (per component, the entries that carry the row)
-    assert rel_rows(ubm.w, g["w"]) < TOL and rel_rows(ubm.mu, g["mu"]) < TOL
-    assert rel_rows(1.0 / ubm.invcov, 1.0 / g["invcov"]) < TOL
+    assert rel_rows(ubm.w, g["w"]) < TOL and rel_rows(1.0 / ubm.invcov, 1.0 / g["invcov"]) < TOL
+    check_first_order(ubm.mu, g["mu"])
     assert rel(ubm.cov_var_ctl, g["ctl"]) < 1e-6
     assert ubm.validate()
 
@@ -376,8 +383,8 @@ def test_em_uniform_dropin_vs_reference_golden(sk):
     assert rel(ubm.mu, g["mu"]) < TOL
     assert rel(1.0 / ubm.invcov, 1.0 / g["invcov"]) < TOL
     # UBM w / mu / covariance element-wise (per component, the entries that carry the row)
-    assert rel_rows(ubm.w, g["w"]) < TOL and rel_rows(ubm.mu, g["mu"]) < TOL
-    assert rel_rows(1.0 / ubm.invcov, 1.0 / g["invcov"]) < TOL
+    assert rel_rows(ubm.w, g["w"]) < TOL and rel_rows(1.0 / ubm.invcov, 1.0 / g["invcov"]) < TOL
+    check_first_order(ubm.mu, g["mu"])
 
 
 def test_one_em_step_from_identical_params_large(sk, eng):
@@ -696,7 +703,8 @@ def test_em_split_device_loop_equals_host_loop(sk, eng):
         accum = copy.deepcopy(host)
         for _ in range(it):
             accum._reset()
-            N, F, S, l = host._global_stats(X)
+            # same conditioning of the float32 logits as the device loop (from the data's moments, Mixture._init)
+            N, F, S, l = host._global_stats(X, host._pack(shift=host._em_shift, ref_var=host._em_ref_var))
             accum.w += N
             accum.mu += F
             accum.invcov += S

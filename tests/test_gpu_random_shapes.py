@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import sidekit_ref as orc
-from conftest import rel_rows
+from conftest import rel_rows, rel_rownorm, check_first_order
 
 pytestmark = pytest.mark.gpu
 
@@ -49,8 +49,9 @@ def test_random_shape_vs_oracle(eng, seed):
     x64 = frames.astype(np.float64)
     rN, rF, rS, rsum = orc.expectation(gmm, x64)
     assert rel(N, rN) < TOL and rel(F, rF) < TOL and rel(S, rS) < TOL, what
-    rows = (rel_rows(N, rN), rel_rows(F, rF), rel_rows(S, rS))         # element-wise, per component row
+    rows = (rel_rows(N, rN), rel_rows(S, rS), rel_rownorm(S, rS))      # element-wise, per component row
     assert max(rows) < TOL, (what, rows)
+    check_first_order(F, rF, what=what)
     assert abs(llk - rsum) <= 1e-6 * abs(rsum), what
     rllk = orc.logsumexp_rows(orc.log_posterior(gmm, x64))[1]
     assert rel(eng.to_host(eng.loglik(X, eng.pack(gmm.w, gmm.mu, gmm.invcov))), rllk) < 1e-5, what
@@ -59,8 +60,8 @@ def test_random_shape_vs_oracle(eng, seed):
     s0, s1 = eng.to_host(s0), eng.to_host(s1)
     r0, r1 = orc.accumulate_stat(gmm, [x64[off[i]:off[i + 1]] for i in range(ns)])
     assert rel(s0, r0) < TOL and rel(s1, r1) < TOL, what
-    rows = (rel_rows(s0, r0), rel_rows(s1, r1))                        # element-wise, per session row
-    assert max(rows) < TOL, (what, rows)
+    assert rel_rows(s0, r0) < TOL, (what, rel_rows(s0, r0))            # element-wise, per session row
+    check_first_order(s1, r1, what=what)
     empty = lens == 0
     assert np.all(s0[empty] == 0) and np.all(s1[empty] == 0), what
     assert np.abs(s0.sum(1) - lens).max() <= 1e-5 * max(lens.max(), 1), what

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import sidekit_ref as orc
-from conftest import golden, rel, rel_rows
+from conftest import golden, rel, rel_rows, rel_rownorm, check_first_order
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -49,9 +49,10 @@ def test_expectation_raw_vs_reference_golden(sk):
     accum = make_ubm(sk, g["w"], g["mu"], g["invcov"])
     accum._reset()
     llk = ubm._expectation(accum, g["cep"])
-    for got, ref in ((accum.w, g["N"]), (accum.mu, g["F"]), (accum.invcov, g["S"])):
-        assert rel(got, ref) < TOL
-        assert rel_rows(got, ref) < TOL
+    for got, ref in ((accum.w, g["N"]), (accum.invcov, g["S"])):
+        assert rel(got, ref) < TOL and rel_rows(got, ref) < TOL and rel_rownorm(got, ref) < TOL
+    assert rel(accum.mu, g["F"]) < TOL
+    check_first_order(accum.mu, g["F"])
     assert abs(llk - float(g["llk"])) < 1e-6 * abs(float(g["llk"]))
     # the T x C matrix and the per-frame log-likelihood of the same frames
     lp = ubm.compute_log_posterior_probabilities(g["cep"][:200])
@@ -75,12 +76,12 @@ def test_accumulate_stat_raw_vs_reference_golden(sk):
     ss.accumulate_stat(ubm=ubm, feature_server=mem_server(sk, table), seg_indices=range(len(names)))
     assert rel(ss.stat0, g["stat0"]) < TOL and rel(ss.stat1, g["stat1"]) < TOL
     assert rel_rows(ss.stat0, g["stat0"]) < TOL          # per session, the components that carry it
-    assert rel_rows(ss.stat1, g["stat1"]) < TOL
+    check_first_order(ss.stat1, g["stat1"])
     C, D = ubm.distrib_nb(), ubm.dim()
     # per (session, component) row of first-order statistics, for the components that hold >= 1 % of the session
     s1, r1 = ss.stat1.reshape(-1, D), g["stat1"].reshape(-1, D)
     keep = (g["stat0"] >= 0.01 * g["stat0"].sum(1, keepdims=True)).reshape(-1)
-    assert rel_rows(s1[keep], r1[keep]) < TOL
+    check_first_order(s1[keep], r1[keep])
 
 
 def test_em_split_raw_vs_reference_golden(sk):
@@ -92,7 +93,8 @@ def test_em_split_raw_vs_reference_golden(sk):
     assert len(llk) == len(g["em_llk"])
     assert np.abs(np.array(llk) - g["em_llk"]).max() < 1e-5 * np.abs(g["em_llk"]).max()
     assert rel(ubm.w, g["em_w"]) < TOL and rel_rows(ubm.w, g["em_w"]) < TOL
-    assert rel(ubm.mu, g["em_mu"]) < TOL and rel_rows(ubm.mu, g["em_mu"]) < TOL
+    assert rel(ubm.mu, g["em_mu"]) < TOL
+    check_first_order(ubm.mu, g["em_mu"])
     assert rel(1.0 / ubm.invcov, 1.0 / g["em_invcov"]) < TOL and rel_rows(1.0 / ubm.invcov, 1.0 / g["em_invcov"]) < TOL
 
 
@@ -111,9 +113,14 @@ def test_centred_c_abi_vs_oracle_shapes(eng, C, D, T):
     flat = eng.to_host(eng.estep(X, packed))
     N, F, S, llk = flat[:C], flat[C:C + C * D].reshape(C, D), flat[C + C * D:C + 2 * C * D].reshape(C, D), flat[-1]
     rN, rF, rS, rl = orc.expectation(gmm, x64)
-    for got, ref in ((N, rN), (F, rF), (S, rS)):
-        assert rel(got, ref) < TOL
-        assert rel_rows(got, ref) < TOL
+    for got, ref in ((N, rN), (S, rS)):
+        assert rel(got, ref) < TOL and rel_rows(got, ref) < TOL and rel_rownorm(got, ref) < TOL
+    assert rel(F, rF) < TOL
+    check_first_order(F, rF)
+    # ... and every entry of F against the sum of the magnitudes it is made of (the scale of a sum with cancellation)
+    pp = orc.logsumexp_rows(orc.log_posterior(gmm, x64))[0]
+    scale = pp.T @ np.abs(x64)
+    assert (np.abs(F - rF) / np.maximum(scale, 1e-300))[scale > 1e-25 * scale.max()].max() < TOL
     assert abs(llk - rl) < 1e-6 * abs(rl)
     # accumulate: two halves added on the device equal the whole
     out = eng.estep(X[:T // 3].contiguous(), packed)
@@ -126,29 +133,37 @@ def test_centred_c_abi_vs_oracle_shapes(eng, C, D, T):
     s0, s1 = eng.to_host(s0), eng.to_host(s1)
     r0, r1 = orc.accumulate_stat(gmm, [x64[off[i]:off[i + 1]] for i in range(len(off) - 1)])
     assert rel(s0, r0) < TOL and rel(s1, r1) < TOL
-    assert rel_rows(s0, r0) < TOL and rel_rows(s1, r1) < TOL
+    assert rel_rows(s0, r0) < TOL
+    check_first_order(s1, r1)
     ll = eng.to_host(eng.loglik(X, eng.pack(gmm.w, gmm.mu, gmm.invcov, shift=packed.shift))).astype(np.float64)
     rll = orc.logsumexp_rows(orc.log_posterior(gmm, x64))[1]
     assert np.abs(ll - rll).max() < 1e-5 * np.abs(rll).max()
 
 
-def test_centring_is_what_makes_raw_features_pass(eng):
-    """The same frames WITHOUT centring miss the bar (why the path exists), and cmvn-like data are left alone."""
+def test_conditioning_is_what_makes_raw_features_pass(eng):
+    """The same frames through a plain image miss the bar by orders of magnitude (why the path exists); centring alone
+    and centring + reference Gaussian each gain; cmvn-like data are not shifted."""
     gmm = orc.raw_gmm(64, 60, seed=41)
     cep = orc.synth_raw_frames(3000, dim=60, clusters=24, seed=42)
     rN, rF, rS, _ = orc.expectation(gmm, cep.astype(np.float64))
     X = eng.upload_frames(cep)
-    plain = eng.to_host(eng.estep(X, eng.pack(gmm.w, gmm.mu, gmm.invcov)))
-    centred = eng.to_host(eng.estep(X, eng.pack(gmm.w, gmm.mu, gmm.invcov, shift=gmm.w @ gmm.mu)))
-    e_plain = rel_rows(plain[64:64 + 64 * 60].reshape(64, 60), rF)
-    e_centred = rel_rows(centred[64:64 + 64 * 60].reshape(64, 60), rF)
-    assert e_centred < TOL
-    assert e_plain > 3 * e_centred, (e_plain, e_centred)
+
+    def err(packed):
+        flat = eng.to_host(eng.estep(X, packed))
+        return max(rel_rows(flat[:64], rN), rel_rownorm(flat[64:64 + 64 * 60].reshape(64, 60), rF),
+                   rel_rows(flat[64 + 64 * 60:64 + 2 * 64 * 60].reshape(64, 60), rS))
+    e_plain = err(eng.pack(gmm.w, gmm.mu, gmm.invcov))
+    e_centred = err(eng.pack(gmm.w, gmm.mu, gmm.invcov, shift=gmm.w @ gmm.mu))
+    e_full = err(eng.pack_stats(gmm.w, gmm.mu, gmm.invcov))
+    print("raw features, worst row error: plain %.1e, centred %.1e, centred + reference %.1e" % (e_plain, e_centred, e_full))
+    assert e_full < TOL
+    assert e_plain > 10 * e_full and e_centred > e_full, (e_plain, e_centred, e_full)
     import sidekit_amd as sk
     m = sk.Mixture()
     g = orc.random_gmm(64, 60, seed=1)
     m.w, m.mu, m.invcov = g.w, g.mu, g.invcov
-    assert m._auto_shift() is None
+    shift, ref_var = m._frame_model()
+    assert shift is None and ref_var is not None
 
 
 def test_sum_log_probabilities_free_functions(sk):

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import sidekit_ref as orc
-from conftest import rel_rows
+from conftest import rel_rows, rel_rownorm
 from conftest import golden
 
 pytestmark = pytest.mark.gpu
@@ -345,9 +345,15 @@ def test_random_tv_shapes_vs_oracle(eng, seed):
     assert rel(_upper_packed(A[:C]), rA) < 1e-4 and rel(Cc, rC) < 1e-4 and rel(_upper_packed(A[C]), rR) < 1e-4, what
     iv, iv_sigma = orc.extract_ivectors(s0, s1, gmm, Fm)
     assert rel(e_h, iv) < 1e-4 and rel(sig, iv_sigma) < 1e-4 and min_cosine(e_h, iv) > 0.9999, what
-    # element-wise on the entries that carry their row: A per component, C per factor, one i-vector per session
-    rows = (rel_rows(_upper_packed(A[:C]), rA), rel_rows(Cc, rC), rel_rows(e_h, iv), rel_rows(sig, iv_sigma))
-    assert max(rows) < 1e-4, (what, rows)
+    # every row on its own scale: A per component, C per factor, one i-vector per session (an i-vector that is itself
+    # the small remainder of a cancelling product -- below 5 % of the largest one -- has no scale of its own: T'f~ is a
+    # float32 product of K = C D terms of both signs, float64 in the reference); iv_sigma >= 1e-300 has no cancellation
+    rows = (rel_rownorm(_upper_packed(A[:C]), rA), rel_rownorm(Cc, rC), rel_rownorm(e_h, iv, floor=0.05),
+            rel_rows(sig, iv_sigma))
+    if S >= 2 * R:      # as for the M-step below: with fewer sessions than factors L is barely regularised by the data
+        assert max(rows) < 1e-4, (what, rows)
+    else:
+        assert max(rows) < 1e-3, (what, rows)
     ft, naug = eng.tv_whiten(dev(eng, s0), dev(eng, s1), gmm.mu.flatten(), gmm.invcov.flatten())
     T32, G = eng.tv_prepare(dev(eng, Fm), C, D)
     e_s, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=False)
