@@ -51,6 +51,10 @@ struct GemmArgs {
     // (they share the B tile in that XCD's L2); 2 = the N tiles of one M tile row do (they share the A tile).
     int swz;
     int swz_tiles_m, swz_tiles_n, swz_batch;  // set by skm_gemm_launch (swz = 3: batched launch, one matrix per XCD at a time)
+    // optional symmetric rank-one term of the epilogue (square C): C[z][m][n] += r1[z * r1_stride + m] * r1[z * r1_stride + n]
+    // after alpha / beta (the e_h e_h' of e_hh = L^-1 + e_h e_h', sidekit/factor_analyser.py:90, fused into X X')
+    const double *r1;
+    long r1_stride;
 };
 
 static inline GemmArgs skm_gemm_args(const void *A, const void *B, void *C, int M, int N, int K, long lda,

@@ -296,6 +296,7 @@ __global__ __launch_bounds__(512, (sizeof(TI) == 4 && ACC64) ? 1 : 2) void k_gem
                     v *= g.alpha;
                     TO *p = C + (long)gm * g.ldc + (g.colmap ? g.colmap[gn] : gn);
                     if (g.beta != 0.0) v += g.beta * (double)(*p);
+                    if (g.r1) v += g.r1[(long)z * g.r1_stride + gm] * g.r1[(long)z * g.r1_stride + gn];
                     *p = (TO)v;
                 }
             }

@@ -184,61 +184,11 @@ __global__ __launch_bounds__(256) void k_chol_diag(T *__restrict__ Mb, long stri
 }
 
 // ------------------------------------------------------------------------------------------------
-// per session: e_h = L^-1 aux (L^-1 symmetric, upper part valid), e_hh = L^-1 + e_h e_h'
+// per session: e_h = L^-1 aux and diag(L^-1) from X = U^-1; e_hh = L^-1 + e_h e_h' is the X X' product with a
+// rank-one epilogue (tv_batch_chain)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_tv_finish(const T *__restrict__ Linv, int R, const double *__restrict__ aux,
-                                                   double *__restrict__ e_h, float *__restrict__ e_h32,
-                                                   double *__restrict__ iv_sigma, float *__restrict__ E)
-{
-    extern __shared__ double sh[];  // aux[R], y[R]
-    double *ax = sh, *y = sh + R;
-    const long b = blockIdx.x;
-    const T *Li = Linv + b * (long)R * R;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int i = t; i < R; i += 256) {
-        ax[i] = aux[b * R + i];
-        y[i] = 0.0;
-    }
-    __syncthreads();
-    // y[j] = sum_{i<=j} U[i][j] ax[i]   (column sweep, coalesced along j)
-    for (int j = t; j < R; j += 256) {
-        double s = 0.0;
-        for (int i = 0; i <= j; ++i) s += (double)Li[(long)i * R + j] * ax[i];
-        y[j] = s;
-    }
-    __syncthreads();
-    // y[i] += sum_{j>i} U[i][j] ax[j]   (row reduce, one wave per row)
-    for (int i = wave; i < R; i += 4) {
-        double s = 0.0;
-        for (int j = i + 1 + lane; j < R; j += 64) s += (double)Li[(long)i * R + j] * ax[j];
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
-        if (lane == 0) y[i] += s;
-    }
-    __syncthreads();
-    for (int i = t; i < R; i += 256) {
-        const double v = y[i];
-        e_h[b * R + i] = v;
-        if (e_h32) e_h32[b * R + i] = (float)v;
-        if (iv_sigma) iv_sigma[b * R + i] = (double)Li[(long)i * R + i] + v * v;
-    }
-    if (E) {
-        float *Eb = E + b * (long)R * R;
-        for (int i = wave; i < R; i += 4) {
-            const int col0 = (i / TV_BLK) * TV_BLK;
-            const double yi = y[i];
-            for (int j = col0 + lane; j < R; j += 64) {
-                // inside the diagonal block the strictly-lower entries mirror the upper ones
-                const double l = (double)((j >= i) ? Li[(long)i * R + j] : Li[(long)j * R + i]);
-                Eb[(long)i * R + j] = (float)(l + yi * y[j]);
-            }
-        }
-    }
-}
-
-// Extraction only: e_h = X (X' aux) and diag(L^-1) = row norms^2 of X, with X = U^-1 (upper triangular) left by
-// the blocked inverse -- the R^3 product X X' is never formed when no accumulator needs L^-1 itself.
+// e_h = X (X' aux) and diag(L^-1) = row norms^2 of X, with X = U^-1 (upper triangular) left by the blocked inverse
+// (extraction with uncertainty stops here: the R^3 product X X' is only formed when the A accumulation needs e_hh).
 template <typename T>
 __global__ __launch_bounds__(256) void k_tv_finish_tri(const T *__restrict__ X, int R, const double *__restrict__ aux,
                                                        double *__restrict__ e_h, float *__restrict__ e_h32,
@@ -510,6 +460,29 @@ static bool tv_chain_f64()
     return e && (strcmp(e, "f64") == 0 || strcmp(e, "F64") == 0);
 }
 
+// Sessions per launch of the per-session chain: the whole batch.  SKM_TV_SUB=<n> cuts it into sub-batches of n sessions
+// -- the experiment that asked whether chains of launches on a sub-batch that fits the 256 MB Infinity Cache beat
+// streaming the batch from HBM.  They do not (round 3, one box, 50 000 sessions: chain 98 ms whole, 112 ms at 1024,
+// 136 at 512, 183 at 256, 279 at 128): the one-wave-per-matrix diagonal kernel and the 64-wide products run under-filled
+// long before the working set is small enough.
+static int tv_chain_sub(int nb)
+{
+    static const int env = [] {
+        const char *e = getenv("SKM_TV_SUB");
+        return e ? atoi(e) : 0;
+    }();
+    return (env > 0 && env < nb) ? env : nb;
+}
+
+static bool tv_poison()
+{
+    static const bool on = [] {
+        const char *e = getenv("SKM_TV_POISON");
+        return e && atoi(e) != 0;
+    }();
+    return on;
+}
+
 struct TvBatch {
     const float *naug, *G;
     const int *cmap;
@@ -530,7 +503,12 @@ static int tv_batch_chain(SkmCtx *ctx, const TvBatch &b, char *mb_, char *linv_,
     const int R = b.R, nb = b.nb;
     const long RR = (long)R * R;
     int rc;
-    SKM_HIP(hipMemsetAsync(Mb, 0, (size_t)nb * RR * sizeof(T), st));
+    // No clearing of the batch's matrices: the L build writes every row from the start of its 4-wide diagonal block,
+    // the diagonal-block kernel reads r <= c only and writes its whole 64 x 64 block (zeros below the diagonal), and
+    // every product of the chain starts its tiles at multiples of 64 and is trimmed to the block-upper part of its
+    // triangular operands -- the blocks below the block diagonal are never read (they cost 32 GB of memset per 50 000
+    // sessions).  SKM_TV_POISON=1 fills them with NaN instead: tests/test_gpu_tv.py proves the claim with it.
+    if (tv_poison()) SKM_HIP(hipMemsetAsync(Mb, 0xFF, (size_t)nb * RR * sizeof(T), st));
     GemmArgs l = skm_gemm_args(b.naug, b.G, Mb, nb, b.NT, b.C, b.ldn, RR, RR);
     l.colmap = b.cmap;
     l.colmap_vec = (R % 4 == 0);
@@ -540,19 +518,42 @@ static int tv_batch_chain(SkmCtx *ctx, const TvBatch &b, char *mb_, char *linv_,
     if ((rc = skm_gemm_launch(ctx, sizeof(T) == 8 ? SKM_GEMM_F32_F64OUT : SKM_GEMM_F32_F32, l, 1, st, "k_gemm_lbuild")))
         return rc;
     const bool solve_only = !b.train && !b.iv_sigma;
-    if ((rc = blocked_inverse<T>(ctx, Mb, b.train ? Linv : nullptr, Tb, nb, R, 1, 1, st, solve_only))) return rc;
+    // The ~25 panel products of the factorisation / inverse each touch a few hundred KB per session; over the whole
+    // batch (4096 sessions: 0.9 GB per launch) every one of them streams from HBM (PMC: 3.2-3.6 TB/s, profiles/
+    // r3_pmc_tv_start.json).  See tv_chain_sub for the sub-batch experiment.
+    const int sub = tv_chain_sub(nb);
+    for (int s0 = 0; s0 < nb; s0 += sub) {
+        const int ns = (nb - s0) < sub ? (nb - s0) : sub;
+        if ((rc = blocked_inverse<T>(ctx, Mb + (long)s0 * RR, (T *)nullptr, Tb, ns, R, 1, 1, st, solve_only))) return rc;
+    }
+    (void)Linv;
     if (solve_only) {
         SkmProfScope ps(ctx, "k_tv_solve", st);
         hipLaunchKernelGGL(k_tv_solve<T>, dim3(nb), dim3(256), (R + 5 * CH_BLK) * sizeof(double), st, Mb, R, b.aux, b.e_h,
                            b.eh32);
-    } else if (!b.train) {
-        SkmProfScope ps(ctx, "k_tv_finish", st);
-        hipLaunchKernelGGL(k_tv_finish_tri<T>, dim3(nb), dim3(256), 2 * R * sizeof(double), st, Mb, R, b.aux, b.e_h, b.eh32,
-                           b.iv_sigma);
     } else {
-        SkmProfScope ps(ctx, "k_tv_finish", st);
-        hipLaunchKernelGGL(k_tv_finish<T>, dim3(nb), dim3(256), 2 * R * sizeof(double), st, Linv, R, b.aux, b.e_h, b.eh32,
-                           b.iv_sigma, b.E);
+        // e_h = X (X' aux) and diag(L^-1) from X = U^-1 alone (two triangular products, R^2 work, X read once)
+        {
+            SkmProfScope ps(ctx, "k_tv_finish", st);
+            hipLaunchKernelGGL(k_tv_finish_tri<T>, dim3(nb), dim3(256), 2 * R * sizeof(double), st, Mb, R, b.aux, b.e_h,
+                               b.eh32, b.iv_sigma);
+        }
+        SKM_HIP(hipGetLastError());
+        if (b.train) {
+            // e_hh = L^-1 + e_h e_h' = X X' + e_h e_h' written ONCE, as the float32 operand of the A accumulation:
+            // the rank-one term rides in the epilogue of the X X' product (L^-1 itself is never stored, and no
+            // kernel reads it back to add e_h e_h')
+            GemmArgs p = skm_gemm_args(Mb, Mb, b.E, R, R, R, R, R, R);
+            p.transB = 1;
+            p.tile_mask = 1;
+            p.ktrim = 2;            // X upper triangular: (X X')[i][j] sums k >= max(i, j)
+            p.sA = p.sB = p.sC = RR;
+            p.r1 = b.e_h;
+            p.r1_stride = R;
+            if ((rc = skm_gemm_launch(ctx, sizeof(T) == 8 ? SKM_GEMM_F64_F32OUT : SKM_GEMM_F32S_F32, p, nb, st,
+                                      "k_gemm_xxt")))
+                return rc;
+        }
     }
     SKM_HIP(hipGetLastError());
     return SKM_OK;

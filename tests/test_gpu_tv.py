@@ -361,3 +361,50 @@ def test_random_tv_shapes_vs_oracle(eng, seed):
     if S >= 2 * R:      # fewer sessions than factors: A_c nearly singular, the solve magnifies the 1e-6 of its inputs
         Fn = eng.to_host(eng.tv_mstep(A_dev, C_dev, C, D, R))
         assert rel(Fn, orc.tv_mstep(rA, rC, rR / S, D, min_div=False)) < 1e-4, what
+
+
+def test_chain_never_reads_below_the_block_diagonal(tmp_path):
+    """The batch's R x R matrices are not cleared before the L build (32 GB of memset per 50 000 sessions at R = 400):
+    nothing may read the blocks below the block diagonal.  SKM_TV_POISON=1 fills the buffer with NaN first; training
+    accumulators, i-vectors (both routes) and the uncertainty must come out bit-identical and finite."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import sidekit_amd
+from oracle import sidekit_ref as orc
+eng = sidekit_amd.default_engine()
+torch = eng.torch
+out = {}
+for tag, (C, D, R, S, batch) in {"r400": (12, 40, 400, 70, 32), "r100": (24, 12, 100, 90, 64), "r33": (5, 8, 33, 40, 7)}.items():
+    rs = np.random.RandomState(R)
+    gmm = orc.random_gmm(C, D, seed=R)
+    post = rs.dirichlet(np.full(C, 0.3), size=S) * rs.randint(100, 3000, size=S)[:, None]
+    s0 = post.astype(np.float32)
+    nrep = np.repeat(post, D, axis=1)
+    s1 = (nrep * gmm.mu.flatten()[None, :] + np.sqrt(nrep / gmm.invcov.flatten()[None, :]) * rs.randn(S, C * D)).astype(np.float32)
+    Fm = 0.1 * rs.randn(C * D, R)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    ft, naug = eng.tv_whiten(dev(s0), dev(s1), gmm.mu.flatten(), gmm.invcov.flatten())
+    T32, G = eng.tv_prepare(dev(Fm), C, D)
+    A = torch.zeros((C + 1, R * R), dtype=torch.float64, device=eng.device)
+    Cc = torch.zeros((R, C * D), dtype=torch.float64, device=eng.device)
+    e_h, sig = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, A_aug=A, Cacc=Cc, uncertainty=True)
+    e_s, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=False)
+    e_u, sig_u = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=True)
+    iu = np.triu_indices(R)
+    out[tag + "_A"] = eng.to_host(A).reshape(C + 1, R, R)[:, iu[0], iu[1]]
+    for k, v in (("C", Cc), ("eh", e_h), ("sig", sig), ("es", e_s), ("eu", e_u), ("sigu", sig_u)):
+        out[tag + "_" + k] = eng.to_host(v)
+np.savez(sys.argv[1], **out)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for poison in ("0", "1"):
+        fn = str(tmp_path / ("p%s.npz" % poison))
+        env = dict(os.environ, SKM_TV_POISON=poison)
+        subprocess.run([sys.executable, "-c", code, fn], check=True, env=env, timeout=300)
+        res[poison] = np.load(fn)
+    for k in res["0"].files:
+        assert np.isfinite(res["1"][k]).all(), k
+        np.testing.assert_array_equal(res["0"][k], res["1"][k], err_msg=k)
