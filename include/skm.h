@@ -207,6 +207,16 @@ int skm_gemm(void *ctx, int kind, const void *A, const void *B, void *C, int M, 
              long ldc, int transA, int transB, double alpha, double beta, int batch, long sA, long sB, long sC,
              void *stream);
 
+/* C = A B (+ C when accumulate) for row-major float32 A[M*K], B[K*N] and C[M*N] float (c_f64 = 0) or double, computed
+ * on the bf16 matrix cores from operands split into three bf16 terms each (x = x1 + x2 + x3 exactly; six of the nine
+ * partial products are kept, the dropped ones are below 2^-26 of the product; float32 accumulation): float32-grade
+ * products at 6/16 of the f32 MFMA time.  This is how skm_tv_estep forms L_s = I + sum_c N_sc G_c
+ * (sidekit/factor_analyser.py:87) and A_c += sum_s N_sc e_hh (sidekit/factor_analyser.py:124) unless SKM_TV_SPLIT=0;
+ * the entry point itself serves tests and timing.  ws_dev: skm_gemm_split_workspace_bytes(M, N, K) bytes. */
+size_t skm_gemm_split_workspace_bytes(int M, int N, int K);
+int skm_gemm_split(void *ctx, const float *A_dev, const float *B_dev, void *C_dev, int M, int N, int K, int c_f64,
+                   int accumulate, void *ws_dev, size_t ws_bytes, void *stream);
+
 /* Workspace bytes of skm_tv_estep (S sessions) / skm_tv_mstep (pass S = 0) for a given batch. */
 size_t skm_tv_workspace_bytes(void *ctx, int C, int D, int R, long S, int batch);
 

@@ -89,3 +89,14 @@ static inline GemmArgs skm_gemm_args(const void *A, const void *B, void *C, int 
 //   SKM_GEMM_F32S_F64OUT the same kernel, C double (rank-sized products whose rank is far from a multiple of 128)
 int skm_gemm_launch(SkmCtx *ctx, int kind, const GemmArgs &g, int batch, hipStream_t st, const char *tag);
 
+
+// ---- float32 GEMM on the bf16 matrix cores by operand splitting (skm_gemm_b3.hip) ----
+// Bytes of the three bf16 planes [3][Kp/8][rows_p][8] of a rows x K operand (K padded to 16, rows to 128).
+size_t skm_b3_plane_bytes(long rows, long K);
+// Split a float32 operand into its planes.  kfast: element (row, k) = src[row * ld + k]; otherwise element (row, k) =
+// src[k * ld + (rowmap ? rowmap[row] : row)].
+int skm_b3_split(SkmCtx *ctx, const float *src, long rows, long K, long ld, int kfast, const int *rowmap, void *dst,
+                 hipStream_t st, const char *tag);
+// C[m * ldc + (colmap ? colmap[n] : n)] (+)= sum_k A(m, k) B(n, k) from split planes; C float or double.
+int skm_b3_gemm(SkmCtx *ctx, const void *Ap, long M, const void *Bp, long N, long K, void *C, int c_f64, long ldc,
+                const int *colmap, int accumulate, hipStream_t st, const char *tag);

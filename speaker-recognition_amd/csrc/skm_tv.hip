@@ -391,8 +391,20 @@ static int blocked_inverse(SkmCtx *ctx, T *Mb, T *out, T *Tb, int nb, int R, int
 
 struct TvWs {
     size_t off_mb, off_linv, off_e, off_tb, off_aux, off_eh32, off_map, off_cs, off_auxs, off_y, total;
+    size_t off_gs, off_ns, off_nt, off_es;      // bf16 x 3 planes of G, of the batch's N (both orientations) and of e_hh
     int ksplit;
 };
+
+// The L build and the A accumulation run on the bf16 matrix cores from operands split into three bf16 terms
+// (skm_gemm_b3.hip) unless SKM_TV_SPLIT=0 (the float32 MFMA products of rounds 1-2).
+static bool tv_split()
+{
+    static const bool on = [] {
+        const char *e = getenv("SKM_TV_SPLIT");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
 
 // split-K factor of the aux = f~ T GEMM.  Every K chunk is a launch of its own (float32 sums over TV_AUX_CHUNK terms,
 // float64 across chunks), and a launch whose 128 x 128 output tiles make only a few rounds over the 2 x CU resident
@@ -446,6 +458,18 @@ static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0, int D = 0)
         w.off_y = off;
         off += skm_align_up((size_t)batch * D * R * sizeof(double), 256);
     }
+    w.off_gs = w.off_ns = w.off_nt = w.off_es = 0;
+    if (S > 0 && C > 0 && tv_split()) {
+        const long NT = tv_tri_cols(R);
+        w.off_gs = off;
+        off += skm_align_up(skm_b3_plane_bytes(NT, C), 256);
+        w.off_ns = off;
+        off += skm_align_up(skm_b3_plane_bytes(batch, C), 256);
+        w.off_nt = off;
+        off += skm_align_up(skm_b3_plane_bytes(C, batch), 256);
+        w.off_es = off;
+        off += skm_align_up(skm_b3_plane_bytes(NT, batch), 256);
+    }
     w.total = off;
     return w;
 }
@@ -484,6 +508,8 @@ static bool tv_poison()
 }
 
 struct TvBatch {
+    const void *Gs;         // bf16 x 3 planes of G over the mapped columns, or NULL (float32 MFMA L build)
+    void *Ns;               // scratch for the planes of this batch's N
     const float *naug, *G;
     const int *cmap;
     const double *aux;
@@ -515,7 +541,13 @@ static int tv_batch_chain(SkmCtx *ctx, const TvBatch &b, char *mb_, char *linv_,
     l.swz = 1;          // the session tiles of one G column tile share it in one XCD's L2
     // K = C float32 MFMA terms per entry, accumulated in float32 like the <= `batch` terms of the A accumulation
     // (the operands are float32 already; ~sqrt(C) * 6e-8 on top of their rounding)
-    if ((rc = skm_gemm_launch(ctx, sizeof(T) == 8 ? SKM_GEMM_F32_F64OUT : SKM_GEMM_F32_F32, l, 1, st, "k_gemm_lbuild")))
+    if (b.Gs) {
+        // the same product on the bf16 matrix cores: N split per batch (33 MB), G split once per call
+        if ((rc = skm_b3_split(ctx, b.naug, nb, b.C, b.ldn, 1, nullptr, b.Ns, st, "k_b3_split"))) return rc;
+        if ((rc = skm_b3_gemm(ctx, b.Ns, nb, b.Gs, b.NT, b.C, Mb, sizeof(T) == 8, RR, b.cmap, 0, st, "k_gemm_lbuild")))
+            return rc;
+    } else if ((rc = skm_gemm_launch(ctx, sizeof(T) == 8 ? SKM_GEMM_F32_F64OUT : SKM_GEMM_F32_F32, l, 1, st,
+                                     "k_gemm_lbuild")))
         return rc;
     const bool solve_only = !b.train && !b.iv_sigma;
     // The ~25 panel products of the factorisation / inverse each touch a few hundred KB per session; over the whole
@@ -665,12 +697,20 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
             if ((rc = skm_gemm_launch(ctx, TV_AUX_KIND, g, 1, st, "k_gemm_aux"))) return rc;
         }
     }
+    const bool split = w.off_gs != 0 || w.off_ns != 0;
+    void *Gs = nullptr;
+    if (split) {
+        Gs = ws + w.off_gs;
+        if ((rc = skm_b3_split(ctx, G, NT, C, RR, 0, cmap, Gs, st, "k_b3_split"))) return rc;
+    }
     const bool chain64 = tv_chain_f64();
     for (long b0 = 0; b0 < S; b0 += batch) {
         const int nb = (int)((S - b0) < batch ? (S - b0) : batch);
         TvBatch tb;
         tb.naug = naug + b0 * ldn;
         tb.G = G;
+        tb.Gs = Gs;
+        tb.Ns = split ? ws + w.off_ns : nullptr;
         tb.cmap = cmap;
         tb.aux = aux + b0 * R;
         tb.e_h = e_h + b0 * R;
@@ -696,7 +736,15 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
             a.colmap = cmap;
             a.colmap_vec = (R % 4 == 0);
             a.swz = 1;      // the component tiles of one e_hh column tile share it
-            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, a, 1, st, "k_gemm_aacc"))) return rc;
+            if (split) {
+                // N' (k = session) and e_hh (k = session, mapped columns) split for this batch, then the product
+                if ((rc = skm_b3_split(ctx, naug + b0 * ldn, C, nb, ldn, 0, nullptr, ws + w.off_nt, st, "k_b3_split")))
+                    return rc;
+                if ((rc = skm_b3_split(ctx, E, NT, nb, RR, 0, cmap, ws + w.off_es, st, "k_b3_split_e"))) return rc;
+                if ((rc = skm_b3_gemm(ctx, ws + w.off_nt, C, ws + w.off_es, NT, nb, A_aug, 1, RR, cmap, 1, st,
+                                      "k_gemm_aacc")))
+                    return rc;
+            } else if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F32_F64OUT, a, 1, st, "k_gemm_aacc"))) return rc;
             SkmProfScope ps(ctx, "k_ehh_colsum", st);
             double *part = reinterpret_cast<double *>(ws + w.off_cs);      // TV_CS_SPLIT x NT doubles
             hipLaunchKernelGGL(k_ehh_colsum, dim3((NT + 255) / 256, TV_CS_SPLIT), dim3(256), 0, st, E, RR, nb, cmap, NT, part);

@@ -65,6 +65,9 @@ SIGNATURES = {
     "skm_gemm": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_long,
                           _c_long, _c_long, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int, _c_long,
                           _c_long, _c_long, _c_void_p]),
+    "skm_gemm_split_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "skm_gemm_split": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                _c_void_p, _c_size_t, _c_void_p]),
     "skm_tv_naug_stride": (_c_int, [_c_int]),
     "skm_tv_workspace_bytes": (_c_size_t, [_c_void_p, _c_int, _c_int, _c_int, _c_long, _c_int]),
     "skm_tv_whiten": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_int, _c_int, _c_void_p,
@@ -573,6 +576,24 @@ class HipEngine(object):
                                       _c_void_p(C.data_ptr()), M, N, K, A.shape[1], B.shape[1], N,
                                       1 if transA else 0, 1 if transB else 0, float(alpha), float(beta), 1, 0, 0, 0,
                                       self._stream()))
+        return C
+
+    def gemm_split(self, A, B, C=None, out_f64=False):
+        """C (+)= A B for float32 device matrices through the bf16 x 3 split kernel (skm_gemm_split)."""
+        torch = self.torch
+        assert A.dtype == B.dtype == torch.float32 and A.is_contiguous() and B.is_contiguous()
+        M, K = A.shape
+        K2, N = B.shape
+        assert K == K2
+        acc = C is not None
+        if C is None:
+            C = torch.empty((M, N), dtype=torch.float64 if out_f64 else torch.float32, device=self.device)
+        assert C.shape == (M, N) and C.is_contiguous()
+        need = self.lib.skm_gemm_split_workspace_bytes(M, N, K)
+        ws = self.workspace(need)
+        self._check(self.lib.skm_gemm_split(self.ctx, self._ptr(A), self._ptr(B), self._ptr(C), M, N, K,
+                                            1 if C.dtype == torch.float64 else 0, 1 if acc else 0, _c_void_p(ws), need,
+                                            self._stream()))
         return C
 
     def feat_sliding_norm(self, Y, Yn, label, seg_host, win=301, reduce=False, compact=False, out_dtype=None):

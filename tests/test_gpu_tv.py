@@ -408,3 +408,28 @@ np.savez(sys.argv[1], **out)
     for k in res["0"].files:
         assert np.isfinite(res["1"][k]).all(), k
         np.testing.assert_array_equal(res["0"][k], res["1"][k], err_msg=k)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (300, 517, 100), (1000, 777, 2048), (64, 4096, 333), (2049, 130, 4096)])
+def test_split_gemm_is_a_float32_product(eng, M, N, K):
+    """skm_gemm_split (three bf16 terms per operand, six bf16 MFMA products, float32 accumulation) against the float64
+    product of the same float32 operands: as close as the float32 MFMA GEMM is -- the split loses nothing that
+    float32 products keep.  Operands with a wide dynamic range and both signs; ragged shapes (padding rows / k)."""
+    torch = eng.torch
+    rs = np.random.RandomState(M + N + K)
+    A = (rs.randn(M, K) * np.exp(rs.uniform(-6, 6, size=(M, K)))).astype(np.float32)
+    B = (rs.randn(K, N) * np.exp(rs.uniform(-6, 6, size=(K, N)))).astype(np.float32)
+    Ad, Bd = torch.from_numpy(A).to(eng.device), torch.from_numpy(B).to(eng.device)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)        # sum of the magnitudes of the terms
+    got = eng.to_host(eng.gemm_split(Ad, Bd)).astype(np.float64)
+    f32 = eng.to_host(eng.gemm(Ad, Bd)).astype(np.float64)
+    e_split = (np.abs(got - ref) / scale).max()
+    e_f32 = (np.abs(f32 - ref) / scale).max()
+    assert e_split < 2e-7 * max(1.0, np.sqrt(K) / 8), (e_split, e_f32)
+    assert e_split < 2.0 * e_f32 + 1e-8, (e_split, e_f32)
+    # float64 output, accumulated onto an existing C
+    C0 = rs.randn(M, N)
+    Cd = torch.from_numpy(C0.copy()).to(eng.device)
+    eng.gemm_split(Ad, Bd, C=Cd)
+    assert (np.abs(eng.to_host(Cd) - (C0 + ref)) / (scale + np.abs(C0))).max() < 2e-7 * max(1.0, np.sqrt(K) / 8)
