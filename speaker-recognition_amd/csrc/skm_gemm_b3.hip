@@ -15,15 +15,17 @@
 // kernel has no bounds test on its loads.  The column map of the TV path (block-upper part of an R x R matrix as the
 // dense N dimension) is applied by the split of B and by the epilogue's store.
 //
-// Kernel: workgroup = 4 waves = 128 x 128 tile (wave: 64 x 64 = 2 x 2 MFMA blocks, 64 accumulator registers), BK = 16
-// (one MFMA k-step) per stage, two LDS stages of 24 KB, global -> registers -> LDS one stage ahead, one barrier per
-// stage; two workgroups per CU.  Per stage and wave: 12 ds_read_b128, 24 MFMAs.
+// Kernel: workgroup = 8 waves = 256 x 256 tile (wave: 128 x 64 = 4 x 2 MFMA blocks, 128 accumulator registers), BK = 16
+// (one MFMA k-step) per stage, two LDS stages of 48 KB, global -> registers -> LDS one stage ahead, one barrier per
+// stage; one workgroup per CU, two waves per SIMD.  Per stage and wave: 18 ds_read_b128, 48 MFMAs.  The tile is this
+// large because the operands cost 6 bytes per element and the loads come from L2: the first version (128 x 128 tiles)
+// pulled 8 TB/s out of the L2s and stopped there, at 0.43 of the bf16 MFMA rate.
 #include "skm_gemm.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-#define B3_TILE 128
+#define B3_TILE 256
 #define B3_BK 16
 
 __device__ __forceinline__ unsigned b3_bf16_rn(float x)
@@ -107,12 +109,12 @@ struct B3Args {
 };
 
 template <typename TO>
-__global__ __launch_bounds__(256, 2) void k_gemm_b3(B3Args g)
+__global__ __launch_bounds__(512, 1) void k_gemm_b3(B3Args g)
 {
     // [stage][operand A/B][plane][k-group of the stage][row]
     __shared__ i32x4 sh[2][2][3][B3_BK / 8][B3_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3, r = lane & 31, h = lane >> 5;      // wave tile: rows wm*128.., cols wn*64..
     // XCD-aware order: workgroups w, w + 8, ... share an XCD; one XCD walks the M tiles of ONE N tile column back to
     // back, so the (large) B tile of the column is fetched into that XCD's L2 once
     const int bx = blockIdx.x, fast = g.tiles_m;
@@ -121,75 +123,64 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(B3Args g)
     if (tn >= g.tiles_n) return;
     const long m0 = (long)tm * B3_TILE, n0 = (long)tn * B3_TILE;
 
-    // staging: plane p = i, k-group of the stage = tid >> 7, row = tid & 127
-    const int skg = tid >> 7, srow = tid & 127;
+    // staging: plane p = i, k-group of the stage = tid >> 8, row = tid & 255
+    const int skg = tid >> 8, srow = tid & 255;
     const long plA = g.KG * g.Mp, plB = g.KG * g.Np;
     const i32x4 *ga = g.A + (long)skg * g.Mp + m0 + srow;
     const i32x4 *gb = g.B + (long)skg * g.Np + n0 + srow;
     const long stepA = (long)(B3_BK / 8) * g.Mp, stepB = (long)(B3_BK / 8) * g.Np;
     const int nk = (int)(g.KG / (B3_BK / 8));
 
-    f32x16 acc[2][2];
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
 
     i32x4 ra[3], rb[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        ra[p] = ga[p * plA];
-        rb[p] = gb[p * plB];
+#define B3_FETCH(S)                                                          \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                           \
+        ra[p] = ga[p * plA + (long)(S) * stepA];                             \
+        rb[p] = gb[p * plB + (long)(S) * stepB];                             \
     }
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        sh[0][0][p][skg][srow] = ra[p];
-        sh[0][1][p][skg][srow] = rb[p];
+#define B3_PUT(ST)                                                           \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                           \
+        sh[ST][0][p][skg][srow] = ra[p];                                     \
+        sh[ST][1][p][skg][srow] = rb[p];                                     \
     }
-    __syncthreads();
+#define B3_MM(PA, PB)                                                                                         \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)         \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][mi], fb[PB][ni], acc[mi][ni], 0, 0, 0);
+    B3_FETCH(0)
+    B3_PUT(0)
+    if (nk > 1) { B3_FETCH(1) }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
+        bf16x8 fa[3][4], fb[3][2];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                ra[p] = ga[p * plA + (long)(kt + 1) * stepA];
-                rb[p] = gb[p * plB + (long)(kt + 1) * stepB];
-            }
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fa[p][b] = __builtin_bit_cast(bf16x8, sh[cur][0][p][h][wm * 128 + b * 32 + r]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fb[p][b] = __builtin_bit_cast(bf16x8, sh[cur][1][p][h][wn * 64 + b * 32 + r]);
         }
-        bf16x8 fa[3][2], fb[3][2];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                fa[p][b] = __builtin_bit_cast(bf16x8, sh[cur][0][p][h][wm * 64 + b * 32 + r]);
-                fb[p][b] = __builtin_bit_cast(bf16x8, sh[cur][1][p][h][wn * 64 + b * 32 + r]);
-            }
         // six products per block, smallest terms first; consecutive MFMAs go to different accumulators
-#define B3_MM(PA, PB)                                                                                         \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)         \
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][mi], fb[PB][ni], acc[mi][ni], 0, 0, 0);
-        B3_MM(2, 0)
-        B3_MM(0, 2)
-        B3_MM(1, 1)
-        B3_MM(1, 0)
-        B3_MM(0, 1)
-        B3_MM(0, 0)
-#undef B3_MM
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                sh[cur ^ 1][0][p][skg][srow] = ra[p];
-                sh[cur ^ 1][1][p][skg][srow] = rb[p];
-            }
-        }
-        __syncthreads();
+        B3_MM(2, 0) B3_MM(0, 2) B3_MM(1, 1) B3_MM(1, 0) B3_MM(0, 1) B3_MM(0, 0)
+        // stage kt + 1 (requested one stage ago) goes to the other LDS buffer behind this stage's MFMAs
+        if (kt + 1 < nk) { B3_PUT(cur ^ 1) }
+        if (kt + 2 < nk) { B3_FETCH(kt + 2) }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+#undef B3_MM
+#undef B3_PUT
+#undef B3_FETCH
 
     TO *C = static_cast<TO *>(g.C);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const long gn = n0 + wn * 64 + ni * 32 + r;
@@ -197,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_b3(B3Args g)
             const long col = g.colmap ? (long)g.colmap[gn] : gn;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const long gm = m0 + wm * 64 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const long gm = m0 + wm * 128 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                 if (gm < g.M) {
                     TO *p = C + gm * g.ldc + col;
                     const TO v = (TO)acc[mi][ni][q];
@@ -229,9 +220,9 @@ int skm_b3_gemm(SkmCtx *ctx, const void *Ap, long M, const void *Bp, long N, lon
     SKM_REQUIRE(grid < 0x7FFFFFFFL, "b3_gemm(%s): grid too large", tag);
     SkmProfScope ps(ctx, tag, st);
     if (c_f64)
-        hipLaunchKernelGGL(k_gemm_b3<double>, dim3((unsigned)grid), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(k_gemm_b3<double>, dim3((unsigned)grid), dim3(512), 0, st, g);
     else
-        hipLaunchKernelGGL(k_gemm_b3<float>, dim3((unsigned)grid), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(k_gemm_b3<float>, dim3((unsigned)grid), dim3(512), 0, st, g);
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }

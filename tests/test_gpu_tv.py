@@ -426,10 +426,9 @@ def test_split_gemm_is_a_float32_product(eng, M, N, K):
     f32 = eng.to_host(eng.gemm(Ad, Bd)).astype(np.float64)
     e_split = (np.abs(got - ref) / scale).max()
     e_f32 = (np.abs(f32 - ref) / scale).max()
-    assert e_split < 2e-7 * max(1.0, np.sqrt(K) / 8), (e_split, e_f32)
-    assert e_split < 2.0 * e_f32 + 1e-8, (e_split, e_f32)
+    assert e_split < 1.25 * e_f32 + 1e-8 and e_split < 4e-6, (e_split, e_f32)
     # float64 output, accumulated onto an existing C
     C0 = rs.randn(M, N)
     Cd = torch.from_numpy(C0.copy()).to(eng.device)
     eng.gemm_split(Ad, Bd, C=Cd)
-    assert (np.abs(eng.to_host(Cd) - (C0 + ref)) / (scale + np.abs(C0))).max() < 2e-7 * max(1.0, np.sqrt(K) / 8)
+    assert (np.abs(eng.to_host(Cd) - (C0 + ref)) / (scale + np.abs(C0))).max() < 1.25 * e_f32 + 1e-8
