@@ -209,7 +209,8 @@ def main():
     ap.add_argument("--frames", type=int, default=10_000_000, help="frames per GPU of the headline workload")
     ap.add_argument("--comps", type=int, default=512)
     ap.add_argument("--dim", type=int, default=60)
-    ap.add_argument("--em2048-frames", type=int, default=12_500_000, help="frames per GPU of the em_c2048 leg")
+    ap.add_argument("--em2048-frames", type=int, default=100_000_000,
+                    help="frames of the em_c2048 leg IN TOTAL (BASELINE configs[2]: 100 M), split over the ranks")
     ap.add_argument("--bw-sessions", type=int, default=50_000, help="sessions of the bw_stats leg, all ranks together")
     ap.add_argument("--tv-sessions", type=int, default=50_000, help="sessions of the tv leg, all ranks together")
     ap.add_argument("--tv-batch", type=int, default=4096, help="sessions per TV E-step batch (training)")
@@ -264,7 +265,11 @@ def main():
     legs = set() if args.no_extra else set(x for x in args.legs.split(",") if x)
     api_stats = None
 
-    T_all = max(T, args.em2048_frames if "em2048" in legs else 0)
+    # cfg3 is ONE job of 100 M frames whatever the GPU count (strong scaling): a rank holds its array_split share,
+    # all of it (24 GB) at N = 1
+    lo_e, hi_e = sk.dist.shard_bounds(args.em2048_frames, world, rank)
+    Te_rank = hi_e - lo_e
+    T_all = max(T, Te_rank if "em2048" in legs else 0)
     X_all = synth_frames_device(torch, T_all, D, seed=1234 + rank, device=dev)
     X = X_all[:T]
     ubm = random_ubm(sk, C, D)
@@ -463,8 +468,9 @@ def main():
 
     if "em2048" in legs:
         note("leg em2048")
-        # ---- EM iteration at the target size (BASELINE configs[2] per-GPU shape, fewer frames): C=2048
-        Ce, Te = 2048, args.em2048_frames
+        # ---- EM iteration at the target size, BASELINE configs[2] WHOLE: C=2048, 100 M frames in total split over the
+        # ranks like numpy.array_split (sidekit_mpi.py:408-410), one all-reduce of the packed statistics per iteration
+        Ce, Te = 2048, Te_rank
         ubm_e = random_ubm(sk, Ce, D, seed=11)
         Xe = X_all[:Te]
         em_iterations(ubm_e, Xe, 1)
@@ -475,10 +481,10 @@ def main():
         eng.profile(False)
         kte = {k: v[1] / v[0] for k, v in prof.items()}
         t_k = sum(kte.values())
-        result["em_c2048"] = {"value": world * Te / dte, "unit": "frames/s", "n_gpus": world,
-                              "ms_per_iteration": 1e3 * dte,
-                              "workload": "UBM EM iteration (E-step + all-reduce + M-step), C=%d, D=%d, %d frames per GPU "
-                                          "(BASELINE configs[2]: 100 M frames over 8 GPUs)" % (Ce, D, Te),
+        result["em_c2048"] = {"value": args.em2048_frames / dte, "unit": "frames/s", "n_gpus": world,
+                              "scaling": "strong", "ms_per_iteration": 1e3 * dte,
+                              "workload": "UBM EM iteration (E-step + all-reduce + M-step), C=%d, D=%d, %d frames in total "
+                                          "(BASELINE configs[2]), %d on rank 0" % (Ce, D, args.em2048_frames, Te),
                               "kernels_ms": {k: round(v, 3) for k, v in kte.items()},
                               "roofline_path": {"bound": "mfma", "achieved": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12,
                                                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -721,6 +727,17 @@ def main():
                       "algorithmic_tflops": float(R) ** 3 * St / (t_f64 * 1e-3) / 1e12 if t_f64 else None,
                       "frac_of_mfma_peak": float(R) ** 3 * St / (t_f64 * 1e-3) / 1e12 / chain_peak if t_f64 else None,
                       "bound": "hbm (64-wide panel products: 8 flop/B in float64, 16 in float32; tools/time_chain_gemm.py)"},
+            # L build and A accumulation (2 C P flop per session each): bf16 x 3 split products on the bf16 matrix cores
+            # (csrc/skm_gemm_b3.hip; float32-grade products, float32 accumulation) unless SKM_TV_SPLIT=0; their rate is
+            # still quoted against the FLOAT32 MFMA peak, so it may exceed 1
+            "split_gemms": {
+                "mode": "f32 mfma" if os.environ.get("SKM_TV_SPLIT", "1") == "0" else "bf16x3 split on the bf16 MFMA",
+                "lbuild_ms": round(prof_tv.get("k_gemm_lbuild", (0, 0.0))[1], 3),
+                "aacc_ms": round(prof_tv.get("k_gemm_aacc", (0, 0.0))[1], 3),
+                "lbuild_frac_of_f32_mfma_peak": (2.0 * Ct * (R * (R + 1) // 2) * St / (prof_tv["k_gemm_lbuild"][1] * 1e-3) / 1e12
+                                                 / PEAK_F32_MFMA_TFLOPS) if prof_tv.get("k_gemm_lbuild", (0, 0))[1] else None,
+                "aacc_frac_of_f32_mfma_peak": (2.0 * Ct * (R * (R + 1) // 2) * St / (prof_tv["k_gemm_aacc"][1] * 1e-3) / 1e12
+                                               / PEAK_F32_MFMA_TFLOPS) if prof_tv.get("k_gemm_aacc", (0, 0))[1] else None},
             "train_kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof_tv.items())},
             "extract_kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof_iv.items())},
             "note": "M-step cost (R x R inverses of the rank's C/N components) is independent of the session count; it is "

@@ -432,3 +432,93 @@ def test_split_gemm_is_a_float32_product(eng, M, N, K):
     Cd = torch.from_numpy(C0.copy()).to(eng.device)
     eng.gemm_split(Ad, Bd, C=Cd)
     assert (np.abs(eng.to_host(Cd) - (C0 + ref)) / (scale + np.abs(C0))).max() < 1.25 * e_f32 + 1e-8
+
+
+def test_full_shape_mstep_and_ivectors_value_check(eng):
+    """BASELINE configs[4] shape -- C = 2048, D = 60, R = 400 -- with 2048 synthetic sessions (well determined: S >= 2 R):
+    the training accumulators and the i-vectors against an independent float64 computation (torch float64 on the
+    device: L_s = I + sum_c N_sc T_c'T_c, LAPACK-class inverse, e_h, e_hh; nothing of libskm), and skm_tv_mstep for 8
+    components against host float64 LAPACK `scipy.linalg.solve(A_c, C_c).T` (sidekit/factor_analyser.py:654-658)."""
+    import scipy.linalg
+    torch = eng.torch
+    C, D, R, S = 2048, 60, 400, 2048
+    gmm = orc.random_gmm(C, D, seed=11)
+    gen = torch.Generator(device=eng.device)
+    gen.manual_seed(77)
+    mu_sv = torch.as_tensor(gmm.mu.flatten(), device=eng.device)
+    sd_sv = torch.as_tensor(1.0 / np.sqrt(gmm.invcov.flatten()), device=eng.device)
+    post = torch.softmax(2.0 * torch.randn(S, C, generator=gen, device=eng.device), dim=1)
+    frames = torch.randint(300, 3000, (S, 1), generator=gen, device=eng.device).to(torch.float64)
+    stat0 = (frames * post).to(torch.float32)
+    n_rep = stat0.repeat_interleave(D, dim=1).to(torch.float64)
+    stat1 = (n_rep * mu_sv + torch.sqrt(n_rep) * sd_sv
+             * torch.randn(S, C * D, generator=gen, device=eng.device, dtype=torch.float64)).to(torch.float32)
+    del n_rep, post
+    Fm = 0.1 * np.random.RandomState(7).randn(C * D, R)
+    T_dev = torch.from_numpy(Fm).to(eng.device)
+    ft, naug = eng.tv_whiten(stat0, stat1, gmm.mu.flatten(), gmm.invcov.flatten())
+    del stat1
+    T32, G = eng.tv_prepare(T_dev, C, D)
+    A_aug = torch.zeros((C + 1, R * R), dtype=torch.float64, device=eng.device)
+    Cacc = torch.zeros((R, C * D), dtype=torch.float64, device=eng.device)
+    e_h, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=1024, A_aug=A_aug, Cacc=Cacc)
+    e_solve, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=2048)
+
+    # ---- independent float64 reference on the device (torch only)
+    comps = [0, 1, 313, 777, 1024, 1500, 2046, 2047]
+    G64 = torch.empty((C, R, R), dtype=torch.float64, device=eng.device)
+    Tc = T_dev.view(C, D, R)
+    for c0 in range(0, C, 256):
+        G64[c0:c0 + 256] = torch.bmm(Tc[c0:c0 + 256].transpose(1, 2), Tc[c0:c0 + 256])
+    N64 = stat0.to(torch.float64)
+    ft64 = ft.to(torch.float64)
+    aux = ft64 @ T_dev                                            # S x R
+    ref_e = torch.empty((S, R), dtype=torch.float64, device=eng.device)
+    ref_A = torch.zeros((len(comps), R, R), dtype=torch.float64, device=eng.device)
+    ref_R = torch.zeros((R, R), dtype=torch.float64, device=eng.device)
+    eye = torch.eye(R, dtype=torch.float64, device=eng.device)
+    for s0 in range(0, S, 256):
+        L = (N64[s0:s0 + 256] @ G64.view(C, R * R)).view(-1, R, R) + eye
+        Linv = torch.linalg.inv(L)
+        e = torch.bmm(Linv, aux[s0:s0 + 256].unsqueeze(2)).squeeze(2)
+        ref_e[s0:s0 + 256] = e
+        ehh = Linv + e.unsqueeze(2) * e.unsqueeze(1)
+        ref_A += torch.einsum("sc,sij->cij", N64[s0:s0 + 256][:, comps], ehh)
+        ref_R += ehh.sum(0)
+        del L, Linv, ehh
+    ref_C = ref_e.t() @ ft64                                      # R x CD
+    del G64, ft64
+
+    def close(got, ref, tol, what):
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < tol, (what, err)
+    # i-vectors: training route (inverse) and extraction route (two triangular solves)
+    for got, what in ((e_h, "e_h (training)"), (e_solve, "e_h (solve)")):
+        close(got, ref_e, 1e-4, what)
+        cos = (got * ref_e).sum(1) / (got.norm(dim=1) * ref_e.norm(dim=1))
+        assert cos.min().item() > 0.9999, (what, cos.min().item())
+        rows = ((got - ref_e).abs().max(1).values / ref_e.abs().max(1).values).max().item()
+        assert rows < 1e-4, (what, "row-normwise", rows)
+    # accumulators: upper triangle of A_c for the 8 components, sum of e_hh, C
+    iu = torch.triu_indices(R, R, device=eng.device)
+    A_full = A_aug.view(C + 1, R, R)
+    for k, c in enumerate(comps):
+        close(A_full[c][iu[0], iu[1]], ref_A[k][iu[0], iu[1]], 1e-4, "A[%d]" % c)
+    close(A_full[C][iu[0], iu[1]], ref_R[iu[0], iu[1]], 1e-4, "sum of e_hh")
+    close(Cacc, ref_C, 1e-4, "C")
+    for c in comps:
+        close(Cacc[:, c * D:(c + 1) * D], ref_C[:, c * D:(c + 1) * D], 1e-4, "C columns of component %d" % c)
+
+    # ---- M-step at the full shape against host LAPACK, from the device's own accumulators
+    A_host = {c: eng.to_host(A_full[c]) for c in comps}
+    C_host = eng.to_host(Cacc)
+    Fn = eng.to_host(eng.tv_mstep(A_aug, Cacc, C, D, R, batch=256))          # destroys A_aug[0:C]
+    for c in comps:
+        Au = np.triu(A_host[c])
+        Ac = Au + np.triu(Au, 1).T
+        want = scipy.linalg.solve(Ac, C_host[:, c * D:(c + 1) * D]).T        # D x R
+        got = Fn[c * D:(c + 1) * D]
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-4, c
+        rows = (np.abs(got - want).max(1) / np.abs(want).max(1)).max()
+        assert rows < 1e-4, (c, "row-normwise", rows)
+    assert np.isfinite(Fn).all()
