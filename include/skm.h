@@ -217,8 +217,9 @@ size_t skm_gemm_split_workspace_bytes(int M, int N, int K);
 int skm_gemm_split(void *ctx, const float *A_dev, const float *B_dev, void *C_dev, int M, int N, int K, int c_f64,
                    int accumulate, void *ws_dev, size_t ws_bytes, void *stream);
 
-/* Workspace bytes of skm_tv_estep (S sessions) / skm_tv_mstep (pass S = 0) for a given batch. */
-size_t skm_tv_workspace_bytes(void *ctx, int C, int D, int R, long S, int batch);
+/* Workspace bytes of skm_tv_estep (S sessions, its `chain` argument) / skm_tv_mstep (pass S = 0, chain = 0) for a
+ * given batch. */
+size_t skm_tv_workspace_bytes(void *ctx, int C, int D, int R, long S, int batch, int chain);
 
 /* Row stride (floats) of the augmented zero-order matrix naug = [stat0 | 1 | zero pad]: C + 1 rounded up
  * to a multiple of 4 so that rows stay 16-byte aligned for the GEMM's vector loads. */
@@ -246,10 +247,22 @@ int skm_tv_prepare(void *ctx, const double *T_dev, int C, int D, int R, float *T
  *   A_aug_dev[(C+1)*R*R] float64 += N' e_hh per component; row C accumulates sum_s e_hh (= _R); full
  *                       [R][R] storage, only blocks on/above the 32-block diagonal are touched; or NULL
  *   Cacc_dev[R*C*D]     float64 += e_h' ftilde; or NULL (A_aug and Cacc go together: training)
+ *   chain               storage / arithmetic type of the per-session matrices L_s, their Cholesky factors and
+ *                       inverses (the reference: float64, scipy.linalg.inv): SKM_TV_CHAIN_F32 costs cond(L_s) * 6e-8
+ *                       on e_h and is 1.5 times faster on that part, SKM_TV_CHAIN_F64 is for long sessions / large
+ *                       loadings; SKM_TV_PRECISE (T64_dev = the CD x R float64 loading matrix, NULL otherwise) also
+ *                       forms G_c, L_s and f~ T in float64 -- with float32 products e_h is off by ~cond(L_s) * 1e-8
+ *                       whatever the chain (measured: cond 3e5 -> 3e-3 normwise, 3e6 -> cosine 0.9993) -- at about
+ *                       half the speed; FactorAnalyser chooses per call from a bound on cond(L_s)
  * Replaces e_on_batch (factor_analyser.py:52-92), e_gather (:109-128), iv_extract_on_batch (:131-142). */
+#define SKM_TV_CHAIN_DEFAULT 0   /* float32, or what the SKM_TV_CHAIN environment variable says */
+#define SKM_TV_CHAIN_F32     1
+#define SKM_TV_CHAIN_F64     2
+#define SKM_TV_PRECISE       3   /* float64 Gram matrices, L build, aux product and chain (needs T64_dev) */
 int skm_tv_estep(void *ctx, const float *naug_dev, const float *ftilde_dev, long S, int C, int D, int R,
                  const float *T32_dev, const float *G_dev, int batch, double *A_aug_dev, double *Cacc_dev,
-                 double *e_h_dev, double *iv_sigma_dev, void *ws_dev, size_t ws_bytes, void *stream);
+                 double *e_h_dev, double *iv_sigma_dev, int chain, const double *T64_dev, void *ws_dev,
+                 size_t ws_bytes, void *stream);
 
 /* TV M-step: F_out_dev[C*D*R] = per component (A_c^-1 C_c)'; A_aug rows 0..C-1 are destroyed.
  * Replaces the solve loop of factor_analyser.py:653-658 (the reference's LU solve of the SPD system is

@@ -102,6 +102,12 @@ __global__ __launch_bounds__(256) void k_cvt_f64_f32(const double *__restrict__ 
         dst[i] = (float)src[i];
 }
 
+__global__ __launch_bounds__(256) void k_cvt_f32_f64(const float *__restrict__ src, double *__restrict__ dst, long n)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = (double)src[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // diagonal block of the blocked Cholesky: U = chol_upper(M_kk) (n <= 64), then W = U^-1 written back in
 // place (upper triangular, strictly lower part zeroed).
@@ -392,6 +398,7 @@ static int blocked_inverse(SkmCtx *ctx, T *Mb, T *out, T *Tb, int nb, int R, int
 struct TvWs {
     size_t off_mb, off_linv, off_e, off_tb, off_aux, off_eh32, off_map, off_cs, off_auxs, off_y, total;
     size_t off_gs, off_ns, off_nt, off_es;      // bf16 x 3 planes of G, of the batch's N (both orientations) and of e_hh
+    size_t off_g64, off_f64, off_n64;           // SKM_TV_PRECISE: float64 Gram matrices, f~ rows and N of a chunk
     int ksplit;
 };
 
@@ -428,7 +435,8 @@ static int tv_ksplit(int cu, long S, int R, int C)
     return ks;
 }
 
-static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0, int D = 0)
+#define TV_PRECISE_ROWS 1024    // sessions per float64 conversion chunk of the aux product (SKM_TV_PRECISE)
+static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0, int D = 0, bool precise = false)
 {
     TvWs w;
     const size_t RR = (size_t)R * R;
@@ -457,6 +465,15 @@ static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0, int D = 0)
     if (D > R) {
         w.off_y = off;
         off += skm_align_up((size_t)batch * D * R * sizeof(double), 256);
+    }
+    w.off_g64 = w.off_f64 = w.off_n64 = 0;
+    if (precise && S > 0 && C > 0) {
+        w.off_g64 = off;
+        off += skm_align_up((size_t)C * RR * sizeof(double), 256);
+        w.off_f64 = off;
+        off += skm_align_up((size_t)(batch < TV_PRECISE_ROWS ? batch : TV_PRECISE_ROWS) * C * D * sizeof(double), 256);
+        w.off_n64 = off;
+        off += skm_align_up((size_t)batch * tv_ldn(C) * sizeof(double), 256);
     }
     w.off_gs = w.off_ns = w.off_nt = w.off_es = 0;
     if (S > 0 && C > 0 && tv_split()) {
@@ -508,6 +525,8 @@ static bool tv_poison()
 }
 
 struct TvBatch {
+    const double *G64;      // SKM_TV_PRECISE: float64 Gram matrices (the L build is a float64 product), or NULL
+    double *n64;            // scratch for the batch's N in float64
     const void *Gs;         // bf16 x 3 planes of G over the mapped columns, or NULL (float32 MFMA L build)
     void *Ns;               // scratch for the planes of this batch's N
     const float *naug, *G;
@@ -541,7 +560,20 @@ static int tv_batch_chain(SkmCtx *ctx, const TvBatch &b, char *mb_, char *linv_,
     l.swz = 1;          // the session tiles of one G column tile share it in one XCD's L2
     // K = C float32 MFMA terms per entry, accumulated in float32 like the <= `batch` terms of the A accumulation
     // (the operands are float32 already; ~sqrt(C) * 6e-8 on top of their rounding)
-    if (b.Gs) {
+    if (b.G64) {
+        // float64 all the way: N (float32 values, exact) widened, G from the float64 loading matrix
+        {
+            SkmProfScope ps(ctx, "k_cvt_f32_f64", st);
+            hipLaunchKernelGGL(k_cvt_f32_f64, dim3(ctx->cu_count * 4), dim3(256), 0, st, b.naug, b.n64, (long)nb * b.ldn);
+        }
+        SKM_HIP(hipGetLastError());
+        SKM_REQUIRE(sizeof(T) == 8, "precise TV E-step needs the float64 chain");
+        GemmArgs l64 = skm_gemm_args(b.n64, b.G64, Mb, nb, b.NT, b.C, b.ldn, RR, RR);
+        l64.colmap = b.cmap;
+        l64.colmap_vec = (R % 2 == 0);
+        l64.swz = 1;
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, l64, 1, st, "k_gemm_lbuild"))) return rc;
+    } else if (b.Gs) {
         // the same product on the bf16 matrix cores: N split per batch (33 MB), G split once per call
         if ((rc = skm_b3_split(ctx, b.naug, nb, b.C, b.ldn, 1, nullptr, b.Ns, st, "k_b3_split"))) return rc;
         if ((rc = skm_b3_gemm(ctx, b.Ns, nb, b.Gs, b.NT, b.C, Mb, sizeof(T) == 8, RR, b.cmap, 0, st, "k_gemm_lbuild")))
@@ -593,12 +625,13 @@ static int tv_batch_chain(SkmCtx *ctx, const TvBatch &b, char *mb_, char *linv_,
 
 extern "C" int skm_tv_naug_stride(int C) { return tv_ldn(C); }
 
-extern "C" size_t skm_tv_workspace_bytes(void *ctx, int C, int D, int R, long S, int batch)
+extern "C" size_t skm_tv_workspace_bytes(void *ctx, int C, int D, int R, long S, int batch, int chain)
 {
     if (R <= 0 || S < 0 || batch <= 0) return 0;
     const int cu = ctx ? static_cast<SkmCtx *>(ctx)->cu_count : 256;
-    return tv_ws(R, S, batch, cu, C, D).total;
+    return tv_ws(R, S, batch, cu, C, D, chain == SKM_TV_PRECISE).total;
 }
+
 
 extern "C" int skm_tv_whiten(void *ctx_, const void *stat0, const void *stat1, int in_f64, long S, int C, int D,
                              const double *mu, const double *sqrt_ic, float *ftilde, float *naug, void *stream)
@@ -641,13 +674,15 @@ extern "C" int skm_tv_prepare(void *ctx_, const double *T, int C, int D, int R, 
 
 extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, long S, int C, int D, int R,
                             const float *T32, const float *G, int batch, double *A_aug, double *Cacc, double *e_h,
-                            double *iv_sigma, void *ws_, size_t ws_bytes, void *stream)
+                            double *iv_sigma, int chain, const double *T64, void *ws_, size_t ws_bytes, void *stream)
 {
     SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
     SKM_REQUIRE(ctx && naug && ftilde && T32 && G && e_h && ws_, "skm_tv_estep: NULL argument");
     SKM_REQUIRE(S > 0 && C > 0 && D > 0 && R > 0 && batch > 0, "skm_tv_estep: bad shape");
     SKM_REQUIRE((A_aug == nullptr) == (Cacc == nullptr), "skm_tv_estep: A_aug and Cacc go together");
-    const TvWs w = tv_ws(R, S, batch, ctx->cu_count, C, D);
+    const bool precise = chain == SKM_TV_PRECISE;
+    SKM_REQUIRE(!precise || T64 != nullptr, "skm_tv_estep: SKM_TV_PRECISE needs the float64 loading matrix");
+    const TvWs w = tv_ws(R, S, batch, ctx->cu_count, C, D, precise);
     if (ws_bytes < w.total) {
         skm_set_error("skm_tv_estep: workspace too small (%zu < %zu)", ws_bytes, w.total);
         return SKM_ERR_WORKSPACE;
@@ -672,7 +707,32 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
     // over chunks of TV_AUX_CHUNK k (plain k loop, no float64 registers: the fast instantiation) and the chunks are
     // added in float64 -- in the output itself (beta = 1) when there are enough output tiles to fill the chip, in
     // split-K slabs when S is small.
-    if (w.ksplit > 1) {
+    double *G64 = nullptr;
+    if (precise) {
+        // Everything e_h depends on in float64, as the reference has it (factor_analyser.py:86-90): G_c = T_c'T_c from
+        // the float64 T, L_s = I + sum_c N_sc G_c and aux = f~ T as float64 products (f~ and N are float32 VALUES in the
+        // reference too -- read from the float32 statistics file -- so widening them is exact).  For long sessions /
+        // large loadings: the float32 products perturb L by 6e-8 |L|, which e_h sees multiplied by cond(L_s).
+        G64 = reinterpret_cast<double *>(ws + w.off_g64);
+        GemmArgs gg = skm_gemm_args(T64, T64, G64, R, R, D, R, R, R);
+        gg.transA = 1;
+        gg.tile_mask = 1;
+        gg.sA = gg.sB = (long)D * R;
+        gg.sC = RR;
+        if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, gg, C, st, "k_gemm_gram"))) return rc;
+        double *f64 = reinterpret_cast<double *>(ws + w.off_f64);
+        const long rows = batch < TV_PRECISE_ROWS ? batch : TV_PRECISE_ROWS;
+        for (long r0 = 0; r0 < S; r0 += rows) {
+            const long nr = (S - r0) < rows ? (S - r0) : rows;
+            {
+                SkmProfScope ps(ctx, "k_cvt_f32_f64", st);
+                hipLaunchKernelGGL(k_cvt_f32_f64, dim3(ctx->cu_count * 8), dim3(256), 0, st, ftilde + r0 * CD, f64, nr * CD);
+            }
+            SKM_HIP(hipGetLastError());
+            GemmArgs g = skm_gemm_args(f64, T64, aux + r0 * R, (int)nr, R, (int)CD, CD, R, R);
+            if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, g, 1, st, "k_gemm_aux"))) return rc;
+        }
+    } else if (w.ksplit > 1) {
         double *slabs = reinterpret_cast<double *>(ws + w.off_auxs);
         const long kc = CD / w.ksplit;
         for (long k0 = 0; k0 < kc; k0 += TV_AUX_CHUNK) {
@@ -697,19 +757,23 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
             if ((rc = skm_gemm_launch(ctx, TV_AUX_KIND, g, 1, st, "k_gemm_aux"))) return rc;
         }
     }
-    const bool split = w.off_gs != 0 || w.off_ns != 0;
+    const bool split = !precise && (w.off_gs != 0 || w.off_ns != 0);
     void *Gs = nullptr;
     if (split) {
         Gs = ws + w.off_gs;
         if ((rc = skm_b3_split(ctx, G, NT, C, RR, 0, cmap, Gs, st, "k_b3_split"))) return rc;
     }
-    const bool chain64 = tv_chain_f64();
+    SKM_REQUIRE(chain >= SKM_TV_CHAIN_DEFAULT && chain <= SKM_TV_PRECISE,
+                "skm_tv_estep: chain must be SKM_TV_CHAIN_DEFAULT / _F32 / _F64 or SKM_TV_PRECISE");
+    const bool chain64 = chain == SKM_TV_CHAIN_DEFAULT ? tv_chain_f64() : chain >= SKM_TV_CHAIN_F64;
     for (long b0 = 0; b0 < S; b0 += batch) {
         const int nb = (int)((S - b0) < batch ? (S - b0) : batch);
         TvBatch tb;
         tb.naug = naug + b0 * ldn;
         tb.G = G;
         tb.Gs = Gs;
+        tb.G64 = G64;
+        tb.n64 = precise ? reinterpret_cast<double *>(ws + w.off_n64) : nullptr;
         tb.Ns = split ? ws + w.off_ns : nullptr;
         tb.cmap = cmap;
         tb.aux = aux + b0 * R;

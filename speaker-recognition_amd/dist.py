@@ -76,6 +76,19 @@ def allreduce_sum_(t):
     return t
 
 
+def allreduce_max_(t):
+    """In-place maximum over ranks (a scalar decision every rank must take alike)."""
+    if is_dist():
+        op = _td().ReduceOp.MAX
+        if _gloo_on_device(t):
+            h = t.cpu()
+            _td().all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            _td().all_reduce(t, op=op)
+    return t
+
+
 def allgather_rows(t, counts):
     """Concatenate per-rank row blocks (rank r contributes counts[r] rows) on every rank: the replacement of the
     reference's Gatherv (sidekit_mpi.py:313-314).  Each rank sends ITS rows only; blocks are padded to the largest

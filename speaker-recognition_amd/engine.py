@@ -69,13 +69,13 @@ SIGNATURES = {
     "skm_gemm_split": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                 _c_void_p, _c_size_t, _c_void_p]),
     "skm_tv_naug_stride": (_c_int, [_c_int]),
-    "skm_tv_workspace_bytes": (_c_size_t, [_c_void_p, _c_int, _c_int, _c_int, _c_long, _c_int]),
+    "skm_tv_workspace_bytes": (_c_size_t, [_c_void_p, _c_int, _c_int, _c_int, _c_long, _c_int, _c_int]),
     "skm_tv_whiten": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_int, _c_int, _c_void_p,
                                _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "skm_tv_prepare": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "skm_tv_estep": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p,
-                              _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t,
-                              _c_void_p]),
+                              _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
+                              _c_void_p, _c_size_t, _c_void_p]),
     "skm_tv_mstep": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p,
                               _c_void_p, _c_size_t, _c_void_p]),
     "skm_moments_workspace_bytes": (_c_size_t, [_c_void_p, _c_int]),
@@ -797,16 +797,24 @@ class HipEngine(object):
                                             _c_void_p(G.data_ptr()), self._stream()))
         return T32, G
 
-    def tv_estep(self, naug, ft, T32, G, C, D, batch=1024, A_aug=None, Cacc=None, uncertainty=False):
+    TV_CHAIN = {None: 0, "default": 0, "f32": 1, "f64": 2, "precise": 3}
+
+    def tv_estep(self, naug, ft, T32, G, C, D, batch=1024, A_aug=None, Cacc=None, uncertainty=False, chain=None,
+                 T64=None):
         """E-step over the sessions of (naug, ft).  Returns (e_h, iv_sigma or None); when A_aug/Cacc are
-        given (training) the accumulators are updated in place."""
+        given (training) the accumulators are updated in place.  chain: "f32" / "f64" = type of the per-session
+        Cholesky / inverse chain (None: float32 unless SKM_TV_CHAIN says otherwise); "precise" (with T64, the float64
+        loading matrix on the device) = everything e_h depends on in float64, for long sessions / large loadings."""
         torch = self.torch
         S = naug.shape[0]
         R = T32.shape[1]
         batch = int(max(1, min(batch, S)))
         e_h = torch.empty((S, R), dtype=torch.float64, device=self.device)
         sig = torch.empty((S, R), dtype=torch.float64, device=self.device) if uncertainty else None
-        need = self.lib.skm_tv_workspace_bytes(self.ctx, C, D, R, S, batch)
+        assert (chain == "precise") == (T64 is not None), "chain='precise' goes with T64"
+        if T64 is not None:
+            assert T64.dtype == torch.float64 and T64.shape == (C * D, R) and T64.is_contiguous()
+        need = self.lib.skm_tv_workspace_bytes(self.ctx, C, D, R, S, batch, self.TV_CHAIN[chain])
         ws = self.workspace(need)
         null = _c_void_p(None)
         self._check(self.lib.skm_tv_estep(self.ctx, _c_void_p(naug.data_ptr()), _c_void_p(ft.data_ptr()), S, C, D, R,
@@ -815,6 +823,8 @@ class HipEngine(object):
                                           _c_void_p(Cacc.data_ptr()) if Cacc is not None else null,
                                           _c_void_p(e_h.data_ptr()),
                                           _c_void_p(sig.data_ptr()) if sig is not None else null,
+                                          self.TV_CHAIN[chain],
+                                          _c_void_p(T64.data_ptr()) if T64 is not None else null,
                                           _c_void_p(ws), need, self._stream()))
         return e_h, sig
 
@@ -823,7 +833,7 @@ class HipEngine(object):
         torch = self.torch
         batch = int(max(1, min(batch, C)))
         F = torch.empty((C * D, R), dtype=torch.float64, device=self.device)
-        need = self.lib.skm_tv_workspace_bytes(self.ctx, C, D, R, 0, batch)
+        need = self.lib.skm_tv_workspace_bytes(self.ctx, C, D, R, 0, batch, 0)
         ws = self.workspace(need)
         self._check(self.lib.skm_tv_mstep(self.ctx, _c_void_p(A_aug.data_ptr()), _c_void_p(Cacc.data_ptr()), C, D, R,
                                           batch, _c_void_p(F.data_ptr()), _c_void_p(ws), need, self._stream()))

@@ -58,6 +58,9 @@ class FactorAnalyser(object):
         self.H = None
         self.Sigma = None
         self._engine = engine
+        # precision of the TV E-step: "auto" (a bound on cond(L_s) decides per call, _estep_chain), "f32", "f64"
+        # (float64 Cholesky / inverse chain only) or "precise" (Gram matrices, L build, f~ T and chain in float64)
+        self.chain_precision = os.environ.get("SKM_TV_PRECISION", "auto")
         if input_file_name is not None:
             fa = FactorAnalyser.read(input_file_name)
             self.mean, self.F, self.G, self.H, self.Sigma = fa.mean, fa.F, fa.G, fa.H, fa.Sigma
@@ -163,6 +166,45 @@ class FactorAnalyser(object):
         naug = naugs[0] if len(naugs) == 1 else torch.cat(naugs, 0)
         return ft, naug, total, local
 
+    # cond(L_s) above which the float32 products of the E-step no longer give cosine >= 0.9999 with room to spare
+    # (tools/tv_long_sessions.py: e_h is off by ~cond * 1e-8 normwise whatever the chain's type; cond 3.6e5 -> 1 - cos
+    # = 9e-6, cond 3e6 -> 7e-4).  The bound below over-estimates cond(L_s) when the components' loadings do not align.
+    PRECISE_ABOVE = 3.0e5
+
+    @staticmethod
+    def chain_cond_bound(eng, T_dev, naug, C, D):
+        """Upper bound of cond(L_s) over the sessions of `naug`: L_s = I + sum_c N_sc T_c'T_c has eigenvalues >= 1 and
+        lambda_max(L_s) <= 1 + sum_c N_sc lambda_max(T_c T_c') -- the D x D Gram matrices' largest eigenvalues by 20
+        power iterations (a few small batched float64 products), then one matrix-vector product with N."""
+        torch = eng.torch
+        if not hasattr(torch, "bmm") or naug is None:
+            return 0.0
+        Tc = T_dev.view(C, D, -1)
+        B = torch.bmm(Tc, Tc.transpose(1, 2))                       # C x D x D
+        v = torch.ones((C, D, 1), dtype=B.dtype, device=B.device)
+        for _ in range(20):
+            v = torch.bmm(B, v)
+            v = v / v.norm(dim=1, keepdim=True).clamp_min(1e-300)
+        lam = 1.1 * torch.bmm(v.transpose(1, 2), torch.bmm(B, v)).reshape(C)      # Rayleigh quotient (+10 %)
+        n = naug[:, :C].to(torch.float64)
+        return 1.0 + float((n @ lam).max().item())
+
+    def _estep_chain(self, T_dev, naug, C, D):
+        """(chain, T64) arguments of engine.tv_estep for this call.  "auto": identical on every rank of a multi-GPU
+        job (the bound is max-reduced), because the ranks' accumulators are summed."""
+        mode = self.chain_precision
+        if mode == "auto":
+            eng = self.engine
+            bound = self.chain_cond_bound(eng, T_dev, naug, C, D) if hasattr(eng, "lib") else 0.0
+            if dist.is_dist():
+                t = eng.torch.tensor([bound], dtype=eng.torch.float64, device=getattr(eng, "device", "cpu"))
+                dist.allreduce_max_(t)
+                bound = float(t.item())
+            mode = "precise" if bound > self.PRECISE_ABOVE else None
+        if mode == "precise":
+            return "precise", T_dev
+        return (mode if mode in ("f32", "f64") else None), None
+
     def _tv_iteration(self, ft, naug, T_dev, C, D, R, total_sessions, min_div, batch):
         """One EM iteration on the device; returns the new loading matrix (device, float64)."""
         eng = self.engine
@@ -170,8 +212,9 @@ class FactorAnalyser(object):
         T32, G = eng.tv_prepare(T_dev, C, D)
         A_aug = torch.zeros((C + 1, R * R), dtype=torch.float64, device=eng.device)
         Cacc = torch.zeros((R, C * D), dtype=torch.float64, device=eng.device)
+        chain, T64 = self._estep_chain(T_dev, naug, C, D)
         if ft is not None:
-            eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, A_aug=A_aug, Cacc=Cacc)
+            eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, A_aug=A_aug, Cacc=Cacc, chain=chain, T64=T64)
         del G
         world = dist.world_size()
         sharded = dist.is_dist() and C % world == 0
@@ -360,7 +403,8 @@ class FactorAnalyser(object):
         T_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(self.F, dtype=np.float64))).to(eng.device)
         T32, G = eng.tv_prepare(T_dev, C, D)
         # without `uncertainty` the device solves L x = aux from the Cholesky factor and never forms U^-1
-        e_h, sig = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=bool(uncertainty))
+        chain, T64 = self._estep_chain(T_dev, naug, C, D)
+        e_h, sig = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=bool(uncertainty), chain=chain, T64=T64)
         return e_h, sig
 
     def extract_ivectors(self, ubm, stat_server_filename, prefix='', batch_size=300, uncertainty=False,

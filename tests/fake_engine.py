@@ -174,7 +174,7 @@ class OracleEngine(object):
     def tv_prepare(self, T, C, D):
         return T.clone(), None
 
-    def tv_estep(self, naug, ft, T32, G, C, D, batch=256, A_aug=None, Cacc=None, uncertainty=False):
+    def tv_estep(self, naug, ft, T32, G, C, D, batch=256, A_aug=None, Cacc=None, uncertainty=False, chain=None, T64=None):
         Fm = T32.numpy()
         R = Fm.shape[1]
         n = naug.numpy().astype(np.float64)[:, :C + 1]

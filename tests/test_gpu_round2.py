@@ -284,8 +284,8 @@ def test_tv_mstep_feature_dimension_larger_than_rank(eng):
                      torch.from_numpy(Cacc.copy()).to(eng.device), C, D, R)
     assert rel(eng.to_host(F), ref) < 1e-10
     assert float(guard.sum().item()) == 7.0 * 4096
-    need = eng.lib.skm_tv_workspace_bytes(eng.ctx, C, D, R, 0, C)
-    small = eng.lib.skm_tv_workspace_bytes(eng.ctx, C, R, R, 0, C)
+    need = eng.lib.skm_tv_workspace_bytes(eng.ctx, C, D, R, 0, C, 0)
+    small = eng.lib.skm_tv_workspace_bytes(eng.ctx, C, R, R, 0, C, 0)
     assert need >= small + C * D * R * 8
 
 

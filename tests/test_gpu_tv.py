@@ -529,3 +529,68 @@ def test_full_shape_mstep_and_ivectors_value_check(eng):
         rows = (np.abs(got - want).max(1) / np.abs(want).max(1)).max()
         assert rows < 1e-4, (c, "row-normwise", rows)
     assert np.isfinite(Fn).all()
+
+
+def test_long_sessions_and_trained_loadings_take_the_precise_path(sk, eng):
+    """ADVICE round 2: sessions of 1e5 frames and a loading matrix after three EM iterations put cond(L_s) at ~3e6;
+    with float32 products (Gram matrices, L build, f~ T) the i-vectors miss the cosine bar whatever the type of the
+    Cholesky chain.  FactorAnalyser's bound on cond(L_s) then selects the all-float64 E-step (chain="precise"), which
+    meets the float64 oracle at 1e-4; short sessions with a fresh T keep the fast path."""
+    torch = eng.torch
+    C, D, R, S, frames = 48, 16, 40, 200, 100000
+    rs = np.random.RandomState(5)
+    gmm = orc.random_gmm(C, D, seed=3)
+    Vtrue = 0.3 * rs.randn(C * D, 6)
+    y = rs.randn(S, 6)
+    post = rs.dirichlet(np.full(C, 0.5), size=S) * frames
+    nrep = np.repeat(post, D, axis=1)
+    sd = 1.0 / np.sqrt(gmm.invcov.flatten())
+    s1 = (nrep * (gmm.mu.flatten()[None, :] + (y @ Vtrue.T) * sd[None, :])
+          + np.sqrt(nrep) * sd[None, :] * rs.randn(S, C * D)).astype(np.float32)
+    s0 = post.astype(np.float32)
+    Fm = 0.1 * rs.randn(C * D, R)
+    for _ in range(3):
+        A, Cc, Rr = orc.tv_accumulate(s0, s1, gmm, Fm, batch_size=300)
+        Fm = orc.tv_mstep(A, Cc, Rr, D, min_div=True)
+    iv, iv_sigma = orc.extract_ivectors(s0, s1, gmm, Fm)
+    rA, rC, rR = orc.tv_accumulate(s0, s1, gmm, Fm, batch_size=300)
+
+    ubm = sk.Mixture()
+    ubm.w, ubm.mu, ubm.invcov = gmm.w, gmm.mu, gmm.invcov
+    ubm.cov_var_ctl = 1.0 / ubm.invcov
+    ubm._compute_all()
+    ss = sk.StatServer()
+    ss.modelset = np.array(["m%d" % i for i in range(S)])
+    ss.segset = ss.modelset.copy()
+    ss.start = np.empty(S, "|O")
+    ss.stop = np.empty(S, "|O")
+    ss.stat0, ss.stat1 = s0.astype(np.float64), s1.astype(np.float64)
+    fa = sk.FactorAnalyser(F=Fm.copy())
+    fa.F = Fm.copy()
+    assert fa.chain_precision == "auto"
+    out, sig = fa.extract_ivectors(ubm, ss, uncertainty=True)
+    cos = min_cosine(out.stat1, iv)
+    assert cos > 0.9999 and rel(out.stat1, iv) < 1e-4 and rel(sig, iv_sigma) < 1e-4, (cos, rel(out.stat1, iv))
+
+    def dev_(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    ft, naug = eng.tv_whiten(dev_(s0), dev_(s1), gmm.mu.flatten(), gmm.invcov.flatten())
+    T_dev = dev_(Fm)
+    bound = sk.FactorAnalyser.chain_cond_bound(eng, T_dev, naug, C, D)
+    index_map = np.repeat(np.arange(C), D)
+    true_cond = max(np.linalg.cond(np.eye(R) + (Fm.T * s0[s, index_map].astype(np.float64)) @ Fm) for s in range(0, S, 20))
+    assert bound >= true_cond and bound > sk.FactorAnalyser.PRECISE_ABOVE, (bound, true_cond)
+    T32, G = eng.tv_prepare(T_dev, C, D)
+    # the float32 products are what fails here, not the chain: both chain types miss, the precise path holds
+    fast = [eng.to_host(eng.tv_estep(naug, ft, T32, G, C, D, batch=64, chain=c)[0]) for c in ("f32", "f64")]
+    assert all(rel(e, iv) > 1e-3 for e in fast), [rel(e, iv) for e in fast]
+    A_aug = torch.zeros((C + 1, R * R), dtype=torch.float64, device=eng.device)
+    Cacc = torch.zeros((R, C * D), dtype=torch.float64, device=eng.device)
+    e_p, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=64, A_aug=A_aug, Cacc=Cacc, chain="precise", T64=T_dev)
+    assert rel(eng.to_host(e_p), iv) < 1e-4
+    A = eng.to_host(A_aug).reshape(C + 1, R, R)
+    assert rel(_upper_packed(A[:C]), rA) < 1e-4 and rel(eng.to_host(Cacc), rC) < 1e-4 and rel(_upper_packed(A[C]), rR * S) < 1e-4
+    # short sessions, fresh loadings: the bound stays below the switch and the fast path is taken
+    naug_short = naug.clone()
+    naug_short[:, :C] *= 2000.0 / frames
+    assert sk.FactorAnalyser.chain_cond_bound(eng, dev_(0.1 * rs.randn(C * D, R)), naug_short, C, D) < sk.FactorAnalyser.PRECISE_ABOVE
