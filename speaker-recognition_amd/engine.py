@@ -986,11 +986,17 @@ class HipEngine(object):
         if n == 0:
             return
         per = max(1, int(chunk_bytes // max(1, t.shape[1] * t.element_size())))
-        key = (t.dtype, per * t.shape[1])
-        if getattr(self, "_pin_key", None) != key:
-            self._pin = [torch.empty(per * t.shape[1], dtype=t.dtype, pin_memory=True) for _ in range(2)]
-            self._pin_ev = [torch.cuda.Event() for _ in range(2)]
-            self._pin_key = key
+        # one pair of page-locked buffers per dtype, sized by capacity: stat0 (width C) and stat1 (width C * D) of one
+        # batch take turns through the same pair instead of re-allocating it on every call
+        need = per * t.shape[1]
+        pins = getattr(self, "_pins", None)
+        if pins is None:
+            pins = self._pins = {}
+        ent = pins.get(t.dtype)
+        if ent is None or ent[0][0].numel() < need:
+            ent = pins[t.dtype] = ([torch.empty(need, dtype=t.dtype, pin_memory=True) for _ in range(2)],
+                                   [torch.cuda.Event() for _ in range(2)])
+        self._pin, self._pin_ev = ent
         st = torch.cuda.current_stream(self.device)
         spans = [(a, min(n, a + per)) for a in range(0, n, per)]
 

@@ -362,6 +362,7 @@ class StatServer(object):
                               "stat0": torch.cat([blk[1] for blk in kept], 0) if len(kept) > 1 else kept[0][1],
                               "stat1": torch.cat([blk[2] for blk in kept], 0) if len(kept) > 1 else kept[0][2],
                               "host": (self.stat0, self.stat1)}
+            self._resident["mark"] = self._fingerprint(self._resident["rows"])
         del kept
 
         if dist.is_dist() and gather:
@@ -391,11 +392,23 @@ class StatServer(object):
                         arr[seg_indices[lo:hi], :] = full[pos:pos + hi - lo]
                     pos += hi - lo
 
+    def _fingerprint(self, rows):
+        """Per-row mark of the host statistics behind a resident copy: the row sums of stat0 and of ~256 evenly spaced
+        columns of stat1.  An in-place edit of the host arrays (ss.stat1 -= m, ss.stat1[i] = ..., ss.stat0 *= k) keeps
+        their identity but not this."""
+        step = max(1, self.stat1.shape[1] // 256)
+        return np.asarray(self.stat0[rows].sum(axis=1) + self.stat1[rows, ::step].sum(axis=1))
+
     def resident_rows(self):
         """(rows, stat0 float32, stat1 float32) device copy of this rank's rows left by
-        accumulate_stat(keep_on_device=True), or None when there is none or the host arrays were replaced since."""
+        accumulate_stat(keep_on_device=True), or None when there is none or the host arrays were replaced or
+        edited in place since (the device copy is then dropped: the host arrays are what the caller sees)."""
         r = self._resident
-        if r is None or r["host"][0] is not self.stat0 or r["host"][1] is not self.stat1:
+        if r is None:
+            return None
+        if r["host"][0] is not self.stat0 or r["host"][1] is not self.stat1 \
+                or not np.array_equal(r["mark"], self._fingerprint(r["rows"]), equal_nan=True):
+            self._resident = None
             return None
         return r["rows"], r["stat0"], r["stat1"]
 

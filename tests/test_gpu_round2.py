@@ -237,6 +237,18 @@ def test_accumulate_stat_keep_on_device_feeds_tv(sk, eng):
     # replacing the host statistics invalidates the device copy
     ss.stat1 = ss.stat1 * 2.0
     assert ss.resident_rows() is None
+    # ... and so does editing them IN PLACE (same arrays, other numbers): row edits and whole-array updates
+    for edit in ("row", "all", "stat0"):
+        ss2 = sk.StatServer(sk.IdMap().set(["spk%d" % (i % 5) for i in range(len(names))], names), ubm=ubm)
+        ss2.accumulate_stat(ubm=ubm, feature_server=fs, seg_indices=range(len(names)), keep_on_device=True)
+        assert ss2.resident_rows() is not None
+        if edit == "row":
+            ss2.stat1[3] = 0.5 * ss2.stat1[3]
+        elif edit == "all":
+            ss2.stat1 -= 0.25
+        else:
+            ss2.stat0 *= 1.5
+        assert ss2.resident_rows() is None, edit
 
 
 # ------------------------------------------------------------------ TV
