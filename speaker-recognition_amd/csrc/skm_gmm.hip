@@ -467,6 +467,7 @@ struct Plan {
     int nct2, nw2, n_cb2, n_fs2, nf2;
     size_t lds2;
     int n_llk;
+    int team_nwv;       // waves per workgroup of the Baum-Welch segment kernel (2: models of one or two component tiles)
     // single-sweep kernel (7..16 component tiles, D <= 63)
     int fused, fused_nwv, fused_blocks, fused_fat, fat_blocks;
     // wide rows (65 <= D+1 <= 160, C <= 128): the fat kernel with ONE component tile per wave, 2 or 4 waves
@@ -604,6 +605,7 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         p->team = (g.CTpad % 16 == 0 && (B == 1 || B == 2 || B == 4 || B == 8) && p->team_per_xcd >= 1 &&
                    D <= 64 && g.NJT <= 2 && (e ? atoi(e) != 0 : 1)) ? 1 : 0;     // D % 4 != 0: run-time-geometry kernels
         p->team_nct = 4;
+        p->team_nwv = 4;
         // EM on wide rows above 128 components: ONE component tile per wave (2 * NJT accumulator tiles), teams of
         // C/128 workgroups; the last workgroup's waves may sit on padding tiles (k_reduce_slabs reads comp < C only)
         if (with_s && !p->team && !p->wide && g.NJT >= 3 && g.NJT <= 5 && D % 4 == 0 && 32 * D <= 5120) {
@@ -628,10 +630,18 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
             // measured against the two sweeps (4 M frames, sessions of 2000): D = 60: C = 64 2.5 vs 1.5 ms (two of four
             // waves idle), C = 96 2.5 vs 2.9, C = 160 3.9 vs 4.9, C = 224 3.9 vs 5.8; D = 132: C = 32 4.3 vs 3.6,
             // C = 64 4.3 vs 6.0, C = 512 15.5 vs 45.1
+            // One or two component tiles (C <= 64, the reference's own UBM): workgroups of TWO waves, two per CU (round
+            // 3) -- every SIMD holds a busy wave where the four-wave workgroup left two on padding tiles (0.28 of the
+            // peak at C = 64, D = 132).  SKM_BW_PAIR=0 restores the old choice.
+            const char *ep = getenv("SKM_BW_PAIR");
+            // measured against the two sweeps (4 M frames, sessions of 2000, ms): C = 64, D = 132: 2.52 vs 6.08 (and 4.50
+            // for the four-wave workgroup); C = 32, D = 132: 2.50 vs 3.65; C = 64, D = 60: 1.46 vs 1.54; but C = 32,
+            // D = 60: 1.42 vs 1.28 and C = 40, D = 20: 0.94 vs 0.71 -- wide rows always, two tiles from 32 columns on
+            const bool pair = g.CT <= 2 && (g.NJT >= 3 || (g.CT == 2 && g.NJT == 2)) && (ep ? atoi(ep) != 0 : 1);
             const int min_ct1 = g.NJT <= 2 ? 3 : 2;
-            const int nct = g.CT <= 4 ? (g.CT >= min_ct1 ? 1 : 0) : (g.CTpad % 8 == 0 ? 2 : 0);
-            const int Bs = nct ? g.CTpad / (4 * nct) : 0;
-            const int per_xcd = Bs > 0 ? (wgs / 8) / Bs : 0;
+            const int nct = pair ? 1 : (g.CT <= 4 ? (g.CT >= min_ct1 ? 1 : 0) : (g.CTpad % 8 == 0 ? 2 : 0));
+            const int Bs = nct ? (pair ? 1 : g.CTpad / (4 * nct)) : 0;
+            const int per_xcd = Bs > 0 ? ((pair ? 2 * wgs : wgs) / 8) / Bs : 0;
             if (rows_ok && nct && (Bs == 1 || ((Bs == 2 || Bs == 4 || Bs == 8) && g.NJT >= 3)) && per_xcd >= 1 &&
                 (e ? atoi(e) != 0 : 1) && (es ? atoi(es) != 0 : 1)) {
                 p->team = 1;
@@ -639,9 +649,12 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
                 p->team_B = Bs;
                 p->team_per_xcd = per_xcd;
                 p->team_wgs = 8 * per_xcd * Bs;
+                p->team_nwv = pair ? 2 : 4;
             }
         }
-        p->team_lds = ((size_t)4 * 32 * g.XS + 4 * 32 + (size_t)4 * p->team_nct * 4 * 64 * 4) * sizeof(float);
+        p->team_lds = p->team_nwv == 2
+                          ? ((size_t)3 * 32 * g.XS + 2 * 32 + (size_t)2 * p->team_nct * 4 * 64 * 4) * sizeof(float)
+                          : ((size_t)4 * 32 * g.XS + 4 * 32 + (size_t)4 * p->team_nct * 4 * 64 * 4) * sizeof(float);
     }
     size_t off = 0;
     p->off_pm = off;
@@ -674,11 +687,11 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         off += skm_align_up(sl, 256);
     }
     p->off_flags = off;     // flags and err are cleared by one memset: keep them adjacent
-    off += skm_align_up((size_t)(p->team ? 8 * p->team_per_xcd * 4 * 4 * p->team_B : 0) * sizeof(unsigned), 256);
+    off += skm_align_up((size_t)(p->team ? 8 * p->team_per_xcd * 4 * p->team_nwv * p->team_B : 0) * sizeof(unsigned), 256);
     p->off_err = off;
     off += 256;
     p->off_xch = off;
-    off += skm_align_up((size_t)(p->team ? 8 * p->team_per_xcd * 4 * 4 * p->team_B * 64 : 0) * sizeof(float), 256);
+    off += skm_align_up((size_t)(p->team ? 8 * p->team_per_xcd * 4 * p->team_nwv * p->team_B * 64 : 0) * sizeof(float), 256);
     p->total = off;
     return SKM_OK;
 }
@@ -1264,7 +1277,20 @@ extern "C" int skm_bw_stats(void *ctx_, const float *X, long T, const int64_t *s
         else if (p.team_B == 4) SKM_BWS_LAUNCH(2, NJT_, 4);                                                       \
         else SKM_BWS_LAUNCH(2, NJT_, 8);                                                                          \
     } while (0)
-            if (p.team_nct != 4) {      // smaller component blocks / wide rows (run-time geometry of the logits ending)
+            if (p.team_nwv == 2) {      // one or two component tiles: two-wave workgroups, two per CU
+#define SKM_BWP_LAUNCH(NJT_, GEN_)                                                                                 \
+    do {                                                                                                          \
+        if ((rc = set_lds(k_seg_team<1, NJT_, 1, true, -1, GEN_, 2>, p.team_lds))) return rc;                     \
+        le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_seg_team<1, NJT_, 1, true, -1, GEN_, 2>), \
+                                        dim3(p.team_wgs), dim3(128), kargs, (unsigned)p.team_lds, st);            \
+    } while (0)
+                if (p.g.NJT == 1) SKM_BWP_LAUNCH(1, true);
+                else if (p.g.NJT == 2) SKM_BWP_LAUNCH(2, true);
+                else if (p.g.NJT == 3) SKM_BWP_LAUNCH(3, false);
+                else if (p.g.NJT == 4) SKM_BWP_LAUNCH(4, false);
+                else SKM_BWP_LAUNCH(5, false);
+#undef SKM_BWP_LAUNCH
+            } else if (p.team_nct != 4) {      // smaller component blocks / wide rows (run-time geometry of the logits ending)
                 if (p.g.NJT == 1) {
                     if (p.team_nct == 1) SKM_BWS_LAUNCH(1, 1, 1);
                     else SKM_BWS_LAUNCH(2, 1, 1);

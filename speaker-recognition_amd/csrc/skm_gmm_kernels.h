@@ -2133,14 +2133,20 @@ __device__ __forceinline__ void gemm_stats_agpr_masked(f32x16 (&acc)[NCT][NJT], 
     }
 }
 
-template <int NCT, int NJT, int B, bool BW, int GEO, bool GEN = (GEO < 0 && NJT <= 2)>
-__global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
+// NWV = 2 (round 3): a workgroup of TWO 512-register waves for models of one or two component tiles (the reference's own
+// UBM: 64 components) -- two such workgroups share a CU, one wave per SIMD, where the four-wave workgroup left two
+// waves on padding tiles.  Its frame ring has three tiles (a team of one workgroup has no partner that runs ahead), so
+// that two workgroups' rings fit the LDS.
+template <int NCT, int NJT, int B, bool BW, int GEO, bool GEN = (GEO < 0 && NJT <= 2), int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, 1) void k_seg_team(TeamArgs a)
 {
-    // PRE floats of a frame tile staged per thread: 32 * D <= PRE * 256 (rows of up to 160 floats at NJT >= 3)
-    constexpr int NF = BW ? NJT : 2 * NJT, NFW = NF * 32, PRE = (NJT >= 3) ? 20 : 8, RING = 4, NC = 4 * B;
+    // PRE floats of a frame tile staged per thread: 32 * D <= PRE * threads (rows of up to 160 floats at NJT >= 3)
+    constexpr int NF = BW ? NJT : 2 * NJT, NFW = NF * 32, PRE = ((NJT >= 3) ? 20 : 8) * (4 / NWV), RING = (NWV == 2) ? 3 : 4,
+                  NC = NWV * B;
+    static_assert(NWV == 4 || (NWV == 2 && B == 1), "two-wave workgroups are teams of one");
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), NWV = 4;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     const TileGeom g = a.g;
     const int tile_floats = 32 * g.XS;
@@ -2148,7 +2154,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
     // members of a team share blockIdx % 8 (blocks are dealt round-robin over the 8 XCDs: same L2)
     const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
     const int member = kk % B, team = xcd * a.teams_per_xcd + kk / B, n_teams = 8 * a.teams_per_xcd;
-    const int me = member * 4 + wave;   // this wave's contribution index = its 128-component block
+    const int me = member * NWV + wave;   // this wave's contribution index = its block of NCT component tiles
 
     float *xs = smem;                                            // [RING][32][XS]
     float *ls = xs + RING * tile_floats + wave * 32;             // wave-private row of 32
@@ -2284,7 +2290,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
         if (t_pf >= 0) stg.load(a.X, t_pf, nv_pf, g.D);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
-        const float *xt = xs + (int)(ni & (RING - 1)) * tile_floats;
+        const float *xt = xs + (int)(ni % RING) * tile_floats;
         SKM_STAMP(5);
         if constexpr (BW) {     // the frames [0, hi_first) of the tile: the whole tile unless a session ends inside it
             gemm_stats_agpr_masked<NJT, NCT>(acc, lg, xt + 4 * h * g.XS + c, g.XS, 0, hi_first, h);
@@ -2306,13 +2312,13 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
             return (int)(left < 32 ? left : 32);
         };
         stg.load(a.X, b, nv(0), g.D);
-        stg.store(xs + (int)(n & (RING - 1)) * tile_floats);
+        stg.store(xs + (int)(n % RING) * tile_floats);
         if (ntile > 1) stg.load(a.X, b + 32, nv(1), g.D);
         __syncthreads();
 #pragma unroll 1
         for (int i = 0; i < ntile; ++i) {
             const unsigned ni = n + (unsigned)i;
-            const int cur = (int)(ni & (RING - 1)), nxt = (cur + 1) & (RING - 1), slot = (int)(ni & 3);
+            const int cur = (int)(ni % RING), nxt = (cur + 1) % RING, slot = (int)(ni & 3);
             const float *xt = xs + cur * tile_floats;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
@@ -2371,6 +2377,9 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
                     lg[ct][4 * q + 2] = o[2];
                     lg[ct][4 * q + 3] = o[3];
                 }
+            // three-tile ring: the slot of tile i + 1 is the one the statistics GEMM of tile i - 2 read at the end of
+            // the previous iteration -- every wave must have left it
+            if constexpr (RING == 3) __syncthreads();
             if (i + 1 < ntile) stg.store(xs + nxt * tile_floats);
             // from here on finish_tile(i-1) requests tile i+2; the first iteration has no finish_tile
             if (i == 0 && ntile > 2) stg.load(a.X, b + 64, nv(2), g.D);
@@ -2420,7 +2429,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
     };
     // after finish_tile(…, hi_first) of a tile [t0, t0 + nvalid) in which the current session ends at hi_first
     auto close_boundary = [&](f32x16 (&lg)[NCT], unsigned ni, long t0, int nvalid, int hi_first) __attribute__((always_inline)) {
-        const float *xt = xs + (int)(ni & (RING - 1)) * tile_floats;
+        const float *xt = xs + (int)(ni % RING) * tile_floats;
         int lo = hi_first;
         close_rows(cur_add);
         cur_add = false;
@@ -2460,7 +2469,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
             return (int)(left <= (long)nv(j) ? left : 32);
         };
         stg.load(a.X, b, nv(0), g.D);
-        stg.store(xs + (int)(n & (RING - 1)) * tile_floats);
+        stg.store(xs + (int)(n % RING) * tile_floats);
         if (ntile > 1) stg.load(a.X, b + 32, nv(1), g.D);
         __syncthreads();
         f32x16 lg[NCT];
@@ -2471,7 +2480,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
 #pragma unroll 1
             for (; i < ntile && !stop; ++i) {
                 const unsigned ni = n + (unsigned)i;
-                const int cur = (int)(ni & (RING - 1)), nxt = (cur + 1) & (RING - 1), slot = (int)(ni & 3);
+                const int cur = (int)(ni % RING), nxt = (cur + 1) % RING, slot = (int)(ni & 3);
                 const float *xt = xs + cur * tile_floats;
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct)
@@ -2517,6 +2526,7 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
                         lg[ct][4 * q + 2] = o[2];
                         lg[ct][4 * q + 3] = o[3];
                     }
+                if constexpr (RING == 3) __syncthreads();     // see run_segment (also covers close_boundary's reads)
                 if (i + 1 < ntile) stg.store(xs + nxt * tile_floats);
                 if (i == 0 && ntile > 2) stg.load(a.X, b + 64, nv(2), g.D);
                 const bool early_flag = i == 0 || i + 1 == ntile;
@@ -2635,6 +2645,8 @@ __global__ __launch_bounds__(256, 1) void k_seg_team(TeamArgs a)
     X(4, 2, 8, true, 0, true) X(4, 2, 8, true, 1, true) X(4, 2, 8, true, 2, true) X(4, 2, 8, true, 3, true)
 #define SKM_SEG_TEAM_INSTANCES_C(X)                                                                              \
     X(1, 1, 1, true, -1) X(1, 2, 1, true, -1) X(1, 3, 1, true, -1) X(1, 4, 1, true, -1) X(1, 5, 1, true, -1)    \
+    X(1, 1, 1, true, -1, true, 2) X(1, 2, 1, true, -1, true, 2) X(1, 3, 1, true, -1, false, 2)                   \
+    X(1, 4, 1, true, -1, false, 2) X(1, 5, 1, true, -1, false, 2)                                               \
     X(2, 1, 1, true, -1) X(2, 2, 1, true, -1)                                                                   \
     X(2, 3, 1, true, -1) X(2, 3, 2, true, -1) X(2, 3, 4, true, -1) X(2, 3, 8, true, -1)                         \
     X(2, 4, 1, true, -1) X(2, 4, 2, true, -1) X(2, 4, 4, true, -1) X(2, 4, 8, true, -1)                         \

@@ -201,6 +201,8 @@ def test_bw_stats_team_kernel_ragged_and_empty_sessions(eng, C, D):
 
 
 @pytest.mark.parametrize("C,D", [(64, 132), (128, 60), (96, 20), (100, 64), (40, 156), (128, 128), (17, 100),    # one tile per wave
+                                 # one or two component tiles: workgroups of two waves, two per CU (three-tile frame ring)
+                                 (64, 60), (33, 20), (20, 13), (64, 39), (5, 7), (48, 64), (64, 96), (64, 160 - 4),
                                  (256, 60), (200, 36), (130, 8), (256, 100), (512, 132), (480, 72), (1024, 96),  # two tiles per wave
                                  (2048, 68),
                                  (448, 60), (1000, 20), (2040, 36),       # four tiles per wave, the last wave on padding tiles
@@ -237,15 +239,17 @@ def test_bw_stats_small_blocks_and_wide_rows(eng, C, D):
     # two float32 paths, each within 1e-4 of the oracle (logits of 2 * 156 terms round further apart than those of 120)
     tol2 = 5e-5 if D <= 64 else 1e-4
     assert rel(s0, eng.to_host(t0)) < tol2 and rel(s1, eng.to_host(t1)) < tol2
-    # the kernel that ran is the one the plan names (a model of one component tile stays on the two sweeps: three of
-    # the four waves of a workgroup would sit on padding)
+    # the kernel that ran is the one the plan names (round 3: a model of one or two component tiles takes the two-wave
+    # workgroups of the segment kernel; it used to stay on the two sweeps)
     eng.profile(True)
     eng.bw_stats(X, off, packed)
     eng.torch.cuda.synchronize()
     prof = eng.profile_read()
     eng.profile(False)
     assert ("k_bw_team" in prof) == (eng.lib.skm_bw_team_count(eng.ctx, C, D) > 0), prof
-    assert ("k_bw_team" in prof) == (not (C == 17)), prof
+    njt, ct = (D + 1 + 31) // 32, (C + 31) // 32
+    if ct <= 2:         # two-wave workgroups: wide rows always, two tiles from 32 columns on; else the two sweeps
+        assert ("k_bw_team" in prof) == (njt >= 3 or (ct == 2 and njt == 2)), prof
 
 
 @pytest.mark.parametrize("C,D", [(2, 156), (16, 132), (100, 159), (256, 159), (1500, 156), (64, 60), (300, 60),   # two sweeps

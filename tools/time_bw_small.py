@@ -12,8 +12,9 @@ X = synth_frames_device(torch, S * L, D, 1234, eng.device)
 ubm = random_ubm(sk, C, D)
 packed = eng.pack(ubm.w, ubm.mu, ubm.invcov)
 off = np.arange(S + 1, dtype=np.int64) * L
-for mode in ("1", "0"):
+for mode, pair in (("1", "1"), ("1", "0"), ("0", "1")):
     os.environ["SKM_BW_SMALL"] = mode
+    os.environ["SKM_BW_PAIR"] = pair
     for _ in range(2): eng.bw_stats(X, off, packed)
     torch.cuda.synchronize()
     eng.profile(True)
@@ -22,5 +23,5 @@ for mode in ("1", "0"):
     k = {n: round(v[1] / v[0], 3) for n, v in eng.profile_read().items()}
     eng.profile(False)
     tot = sum(k.values())
-    print("C=%d D=%d SKM_BW_SMALL=%s total %.3f ms  %.1f TF algorithmic (%.2f of peak)  %s" % (
-        C, D, mode, tot, 6.0 * D * C * S * L / tot / 1e9, 6.0 * D * C * S * L / tot / 1e9 / 157.3, k), flush=True)
+    print("C=%d D=%d SKM_BW_PAIR=%s SKM_BW_SMALL=%s total %.3f ms  %.1f TF algorithmic (%.2f of peak)  %s" % (
+        C, D, pair, mode, tot, 6.0 * D * C * S * L / tot / 1e9, 6.0 * D * C * S * L / tot / 1e9 / 157.3, k), flush=True)
