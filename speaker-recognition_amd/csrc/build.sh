@@ -24,3 +24,8 @@ for p in "${pids[@]:-}"; do
 done
 "${HIPCC}" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "${OUT}"
 echo "built ${OUT}"
+# static check of the generated ISA for the wait states around the asm MFMAs and the LDS-direct loads
+# (tools/isa_lint.py; about a minute).  SKM_SKIP_LINT=1 skips it, e.g. while iterating on a timing variant.
+if [ "${SKM_SKIP_LINT:-0}" != "1" ]; then
+    python3 "${HERE}/../../tools/isa_lint.py" "${OUT}"
+fi

@@ -123,6 +123,20 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// one settle for all accumulators: only the last MFMA can still be in flight (each earlier one issued >= 64
+// cycles before it); 20 wait states cover the 18 a 16-pass MFMA needs before a VALU may read its result
+template <int NCT>
+__device__ __forceinline__ void vgpr_settle_all(f32x16 (&lg)[NCT])
+{
+    static_assert(NCT == 1 || NCT == 2 || NCT == 4, "operand lists are written for 1, 2 or 4 accumulators");
+    if constexpr (NCT == 4)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lg[0]), "+v"(lg[1]), "+v"(lg[2]), "+v"(lg[3]));
+    else if constexpr (NCT == 2)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lg[0]), "+v"(lg[1]));
+    else
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lg[0]));
+}
+
 // GEMM 1: lg[ct] += x~ tile (32 frames x 2D) . W block.  xs_row = xs + c*XS, Wl4 = W block + lane.
 template <int NCT>
 __device__ __forceinline__ void gemm_logits(f32x16 (&lg)[NCT], const float *xs_row, int h, const f32x4 *Wl4,
@@ -159,6 +173,12 @@ __device__ __forceinline__ void gemm_logits(f32x16 (&lg)[NCT], const float *xs_r
             lg[ct] = SKM_MFMA32(a4[3], wm[3], lg[ct]);
         }
     }
+    // these are builtin MFMAs and the compiler pads its own readers, but the first readers of lg are inline asm
+    // (vmax2 / vmax3 of tile_row_max), which it does not: k_estep_fused<2> took its row maxima straight behind the last
+    // MFMA (tools/isa_lint.py rule i; harmless there, the maximum only centres the exponentials, but not by design)
+#ifndef SKM_LINT_DEMO_LOGITS_NO_SETTLE
+    vgpr_settle_all<NCT>(lg);
+#endif
 }
 
 
@@ -1124,20 +1144,6 @@ __device__ __forceinline__ void wset_mma_pf(f32x16 (&lg)[NCT], const WSet<NCT> &
     }
 }
 
-// one settle for all accumulators: only the last MFMA can still be in flight (each earlier one issued >= 64
-// cycles before it); 20 wait states cover the 18 a 16-pass MFMA needs before a VALU may read its result
-template <int NCT>
-__device__ __forceinline__ void vgpr_settle_all(f32x16 (&lg)[NCT])
-{
-    static_assert(NCT == 1 || NCT == 2 || NCT == 4, "operand lists are written for 1, 2 or 4 accumulators");
-    if constexpr (NCT == 4)
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lg[0]), "+v"(lg[1]), "+v"(lg[2]), "+v"(lg[3]));
-    else if constexpr (NCT == 2)
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lg[0]), "+v"(lg[1]));
-    else
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lg[0]));
-}
-
 // mixed tail group (held in wl) with the loads of pair 0 for the next tile spread between the MFMAs.
 // Branch-free, and the results are settled before the function returns: wherever control flow merges
 // behind asm MFMAs the compiler places register copies that would read the accumulators too early.
@@ -1149,8 +1155,15 @@ __device__ __forceinline__ void wset_tail_pf(f32x16 (&lg)[NCT], const f32x4 (&wl
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         if (TAIL) {
+            // where this block follows a branch the compiler may have just copied lg[ct] into the tuple it names here
+            // (seen at NCT = 2: v_mov_b64 one wait state ahead of the MFMA that reads it as SrcC; tools/isa_lint.py rule ii)
+#ifndef SKM_LINT_DEMO_TAIL_NO_PAD
+            mfma_vgpr_after_valu(lg[ct], xt[0], wl[ct][0]);
+#else
+            mfma_vgpr(lg[ct], xt[0], wl[ct][0]);
+#endif
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mfma_vgpr(lg[ct], xt[i], wl[ct][i]);
+            for (int i = 1; i < 4; ++i) mfma_vgpr(lg[ct], xt[i], wl[ct][i]);
         }
         nxt.l[ct] = wfrag_load(ws, (ct * NG) * 1024);
         nxt.q[ct] = wfrag_load(ws, (ct * NG + 1) * 1024);
@@ -1195,6 +1208,11 @@ __device__ __forceinline__ void gemm_logits_fat(f32x16 (&lg)[NCT], WSet<NCT> &wa
     const bool tail = (GEO >= 0) ? ((GEO & 1) != 0) : (g.tail != 0);
     if (odd) {      // pair q sits in wa, the tail group goes to wb
         wset_mma_pf<NCT>(lg, wa, xa, wb, Wg4, NG, NP, q + 1);
+        // runtime geometry: the branch on `tail` follows, and the compiler opens one of its arms with copies of lg
+        // three wait states behind the last MFMA (tools/isa_lint.py rule i found them in every GEO = -1 instance)
+#ifndef SKM_LINT_DEMO_ODD_NO_SETTLE
+        if (GEO < 0) vgpr_settle_all<NCT>(lg);
+#endif
         if (tail)
             wset_tail_pf<NCT, true>(lg, wb.l, xt, wa, Wg4, NG);
         else
@@ -1409,20 +1427,14 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
 
     SKM_TRACE_DECL;
     int cur = 0;
-    for (long base = ta; base < tb; base += a.flush_tiles) {
-    const long end = (base + a.flush_tiles < tb) ? base + a.flush_tiles : tb;
-#pragma unroll 1
-    for (long tile = base; tile < end; ++tile) {
-        const long t0 = tile << 5;
-        const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
-        const int nxt = (cur == 2) ? 0 : cur + 1;
-        const int pslot = (int)((tile - ta) & 1);
-        const bool has_next = tile + 1 < tb;
-        SKM_TRACE_TILE;
-        SKM_STAMP(0);
-        const float *xt = xs + cur * tile_floats;
-
-        f32x16 lg[NCT];
+    // The logits of a tile start from the constants kc.  The splat for the NEXT tile is issued at the end of a tile,
+    // behind the statistics GEMM, where it costs what it cost at the top (it runs in the shadow of the last MFMA
+    // either way) and puts 16 NCT + 4 wait states between that MFMA and the loop's exit edge: the compiler moves
+    // accumulators between registers there, ahead of flush_slab_agpr's own settles (v_accvgpr_read of the last-written
+    // tuple 10 wait states behind its MFMA; tools/isa_lint.py rule i), and a wait placed behind the loop, or in an
+    // `if (last tile)`, lands after those moves or costs the allocator its AGPR assignment.
+    f32x16 lg[NCT];
+    auto logits_start = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             // opaque per tile: otherwise the 64-register splat is hoisted out of the loop, spilled, and
@@ -1438,6 +1450,26 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
         }
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
+    };
+    for (long base = ta; base < tb; base += a.flush_tiles) {
+    const long end = (base + a.flush_tiles < tb) ? base + a.flush_tiles : tb;
+#ifndef SKM_LINT_DEMO_EXIT_NO_SETTLE
+    logits_start();
+#endif
+#pragma unroll 1
+    for (long tile = base; tile < end; ++tile) {
+        const long t0 = tile << 5;
+        const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
+        const int nxt = (cur == 2) ? 0 : cur + 1;
+        const int pslot = (int)((tile - ta) & 1);
+        const bool has_next = tile + 1 < tb;
+        SKM_TRACE_TILE;
+        SKM_STAMP(0);
+        const float *xt = xs + cur * tile_floats;
+
+#ifdef SKM_LINT_DEMO_EXIT_NO_SETTLE
+        logits_start();
+#endif
 #ifdef SKM_TRACE
         gemm_logits_fat<NCT, GEO>(lg, wa, xt + c * g.XS, h, Wg4, g, trace_now ? a.trace + wave * 16 : nullptr);
 #elif !defined(SKM_ABL_NOLOGITS)
@@ -1506,6 +1538,9 @@ __global__ __launch_bounds__(256, 1) void k_estep_fat(FusedArgs a)
         gemm_stats_agpr<NJT, NCT>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
 #endif
         SKM_STAMP(6);
+#ifndef SKM_LINT_DEMO_EXIT_NO_SETTLE
+        logits_start();     // the next tile's, and the wait states in front of the exit edge (see above the loop)
+#endif
         wave_lds_fence();
         cur = nxt;
     }
@@ -1604,15 +1639,9 @@ __global__ __launch_bounds__(64, NCT == 1 ? 2 : 1) void k_estep_solo(FusedArgs a
     const int frame = acc_row((c >> 1) & 15, h);
     bool first = true;
     int cur = 0;
-    for (long base = ta; base < tb; base += a.flush_tiles) {
-    const long end = (base + a.flush_tiles < tb) ? base + a.flush_tiles : tb;
-#pragma unroll 1
-    for (long tile = base; tile < end; ++tile) {
-        const int nvalid = valid_in(tile << 5);
-        const float *xt = xs + cur * tile_floats;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this tile's frames are in LDS
-
-        f32x16 lg[NCT];
+    // as in k_estep_fat: the splat of the next tile's logits closes every tile, in front of the loop's exit edge
+    f32x16 lg[NCT];
+    auto logits_start = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             float k = kcv[ct];
@@ -1622,6 +1651,18 @@ __global__ __launch_bounds__(64, NCT == 1 ? 2 : 1) void k_estep_solo(FusedArgs a
         }
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
+    };
+    for (long base = ta; base < tb; base += a.flush_tiles) {
+    const long end = (base + a.flush_tiles < tb) ? base + a.flush_tiles : tb;
+    logits_start();
+#pragma unroll 1
+    for (long tile = base; tile < end; ++tile) {
+        const int nvalid = valid_in(tile << 5);
+        const float *xt = xs + cur * tile_floats;
+#ifndef SKM_LINT_DEMO_NO_DMA_WAIT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this tile's frames are in LDS
+#endif
+
         gemm_logits_fat<NCT, GEO>(lg, wa, xt + c * g.XS, h, Wg4, g);
 
         // exact per-frame maximum over all components, e = 2^(l - max), per-frame sum of e
@@ -1656,6 +1697,7 @@ __global__ __launch_bounds__(64, NCT == 1 ? 2 : 1) void k_estep_solo(FusedArgs a
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) valu_to_mfma(lg[ct]);
         gemm_stats_agpr<NJT, NCT, true, VACC>(acc, lg, xt + 4 * h * g.XS + c, g.XS);
+        logits_start();
         wave_lds_fence();
         cur ^= 1;
     }
