@@ -373,6 +373,26 @@ size_t skm_label_index_workspace_bytes(long T);
 int skm_label_index(void *ctx, const uint8_t *label_dev, long T, const int64_t *seg_off_dev, int S, int64_t *idx_dev,
                     int64_t *coff_dev, void *ws_dev, size_t ws_bytes, void *stream);
 
+/* ---- One process, several GPUs -------------------------------------------------------------------------------------
+ * The reference fans its hot loops out from ONE Python process (num_thread / multiprocessing: sidekit/mixture.py:570-588,
+ * sidekit/sidekit_wrappers.py:141-214) or over MPI ranks (sidekit/sidekit_mpi.py: Reduce + bcast of the EM accumulators
+ * :455-481, of the TV accumulators :186-214, Gatherv of the i-vectors :313-314).  For a caller that stays one plain
+ * process: one SkmCtx and one host thread per GPU, and these collectives between the GPUs -- RCCL communicators from
+ * ncclCommInitAll (librccl is opened at run time: SKM_ERR_UNSUPPORTED when the machine has none), every call issues the
+ * operation for ALL devices inside one group, on streams[i] of device i, asynchronously.  Pointer lists have
+ * skm_comm_size() entries in the order of `devices`.  Not thread-safe per communicator: one caller at a time. */
+int skm_comm_init_all(int ndev, const int *devices, void **comm_out);
+int skm_comm_size(void *comm);
+int skm_comm_destroy(void *comm);
+/* in place over `count` float64 values; op 0 = sum, 1 = maximum */
+int skm_allreduce_f64(void *comm, void *const *bufs_dev, size_t count, int op, void *const *streams);
+/* sum of [ndev * recv_count] float64 values, device i keeps slice i in recv_dev[i] */
+int skm_reduce_scatter_f64(void *comm, void *const *send_dev, void *const *recv_dev, size_t recv_count,
+                           void *const *streams);
+/* recv_dev[i] (ndev * send_bytes bytes) = the send buffers of all devices in device order */
+int skm_allgather_bytes(void *comm, void *const *send_dev, void *const *recv_dev, size_t send_bytes,
+                        void *const *streams);
+
 #ifdef __cplusplus
 }
 #endif

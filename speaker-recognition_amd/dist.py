@@ -1,10 +1,13 @@
-"""Thin torch.distributed helpers: one process per GPU, RCCL ("nccl" backend) over xGMI on the
-GPU box, gloo in the CPU tests.  Replaces sidekit/sidekit_mpi.py's Reduce/bcast pattern
+"""Thin collective helpers.  Two ways to be a rank: one process per GPU under torch.distributed (RCCL = the "nccl"
+backend over xGMI on the GPU box, gloo in the CPU tests), or one THREAD per GPU of a single process (`team.py`:
+SKM_DEVICES, grouped RCCL calls through libskm).  Replaces sidekit/sidekit_mpi.py's Reduce/bcast pattern
 (sidekit_mpi.py:455-481, 186-214): every rank all-reduces ONE packed float64 buffer and then runs
 the identical deterministic M-step, so no broadcast is needed."""
 import os
 
 import numpy as np
+
+from . import team as _team
 
 
 def _td():
@@ -16,6 +19,9 @@ def is_dist():
     """True when torch.distributed is initialised with more than one rank.  SKM_FORCE_DIST=1 also takes the
     collective code paths in a world of ONE rank (tests/test_gpu_rccl.py: the RCCL calls, buffer layouts and
     the component-sharded M-step run for real on a single-GPU box)."""
+    tm, _ = _team.current()
+    if tm is not None:
+        return tm.world > 1 or os.environ.get("SKM_FORCE_DIST") == "1" or os.environ.get("SKM_TEAM_FORCE") == "1"
     try:
         td = _td()
         if not (td.is_available() and td.is_initialized()):
@@ -26,11 +32,22 @@ def is_dist():
 
 
 def rank():
+    tm, r = _team.current()
+    if tm is not None:
+        return r
     return _td().get_rank() if is_dist() else 0
 
 
 def world_size():
+    tm, _ = _team.current()
+    if tm is not None:
+        return tm.world
     return _td().get_world_size() if is_dist() else 1
+
+
+def in_team():
+    """True in a rank THREAD of a single process (the ranks then share the caller's host objects)."""
+    return _team.current()[0] is not None
 
 
 def shard_bounds(n, k=None, r=None):
@@ -65,6 +82,12 @@ def _gloo_on_device(t):
 
 def allreduce_sum_(t):
     """In-place sum over ranks of a torch tensor (device tensor -> RCCL, CPU tensor -> gloo)."""
+    tm, r = _team.current()
+    if tm is not None:
+        if is_dist():
+            PAYLOAD["all_reduce"] += _nbytes(t)
+            tm.allreduce_(r, t, "sum")
+        return t
     if is_dist():
         PAYLOAD["all_reduce"] += _nbytes(t)
         if _gloo_on_device(t):
@@ -78,6 +101,11 @@ def allreduce_sum_(t):
 
 def allreduce_max_(t):
     """In-place maximum over ranks (a scalar decision every rank must take alike)."""
+    tm, r = _team.current()
+    if tm is not None:
+        if is_dist():
+            tm.allreduce_(r, t, "max")
+        return t
     if is_dist():
         op = _td().ReduceOp.MAX
         if _gloo_on_device(t):
@@ -96,7 +124,8 @@ def allgather_rows(t, counts):
     if not is_dist():
         return t
     import torch
-    td = _td()
+    tm, tr = _team.current()
+    td = _td() if tm is None else None
     counts = [int(c) for c in counts]
     assert t.shape[0] == counts[rank()], (t.shape, counts, rank())
     w, m = len(counts), max(counts)
@@ -108,6 +137,11 @@ def allgather_rows(t, counts):
         send = torch.zeros((m,) + tail, dtype=t.dtype, device=t.device)
         send[:t.shape[0]] = t
     PAYLOAD["all_gather"] += _nbytes(send)
+    if tm is not None:
+        out = tm.allgather(tr, send)
+        if all(c == m for c in counts):
+            return out
+        return torch.cat([out[r * m:r * m + counts[r]] for r in range(w)], dim=0)
     out = torch.empty((w * m,) + tail, dtype=t.dtype, device=t.device)
     if td.get_backend() == "nccl":
         td.all_gather_into_tensor(out, send)
@@ -129,12 +163,15 @@ def reduce_scatter_rows(t):
     if not is_dist():
         return t
     import torch
-    td = _td()
     w, r = world_size(), rank()
     n = t.shape[0] // w
     assert n * w == t.shape[0]
     t = t.contiguous()
     PAYLOAD["reduce_scatter"] += _nbytes(t)
+    tm, tr = _team.current()
+    if tm is not None:
+        return tm.reduce_scatter(tr, t)
+    td = _td()
     if td.get_backend() == "nccl":
         out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         td.reduce_scatter_tensor(out, t)
@@ -148,5 +185,8 @@ def reduce_scatter_rows(t):
 
 
 def barrier():
-    if is_dist():
+    tm, _ = _team.current()
+    if tm is not None:
+        tm.barrier()
+    elif is_dist():
         _td().barrier()

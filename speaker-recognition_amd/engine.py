@@ -92,6 +92,15 @@ SIGNATURES = {
     "skm_feat_postproc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_long, _c_void_p, _c_int, _c_void_p, _c_void_p,
                                    _c_int, _c_long, _c_int, _c_int, _dp, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p,
                                    _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    # one process, several GPUs (team.py)
+    "skm_comm_init_all": (_c_int, [_c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p)]),
+    "skm_comm_size": (_c_int, [_c_void_p]),
+    "skm_comm_destroy": (_c_int, [_c_void_p]),
+    "skm_allreduce_f64": (_c_int, [_c_void_p, ctypes.POINTER(_c_void_p), _c_size_t, _c_int, ctypes.POINTER(_c_void_p)]),
+    "skm_reduce_scatter_f64": (_c_int, [_c_void_p, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_size_t,
+                                        ctypes.POINTER(_c_void_p)]),
+    "skm_allgather_bytes": (_c_int, [_c_void_p, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p), _c_size_t,
+                                     ctypes.POINTER(_c_void_p)]),
 }
 
 _lib = None
@@ -1106,8 +1115,13 @@ _default_engine = None
 
 
 def default_engine():
-    """The process-wide engine on the current CUDA/HIP device (LOCAL_RANK aware)."""
+    """The process-wide engine on the current CUDA/HIP device (LOCAL_RANK aware); inside a rank thread of a
+    single-process team (team.py) the engine of that rank's GPU."""
     global _default_engine
+    from . import team as _team
+    mine = _team.engine_of_thread()
+    if mine is not None:
+        return mine
     if _default_engine is None:
         _default_engine = HipEngine()
     return _default_engine

@@ -16,6 +16,7 @@ import numpy as np
 
 from . import dist
 from . import engine as _engine
+from .team import fanout
 from .mixture import Mixture, _has_h5py, _h5
 from .statserver import StatServer, STAT_TYPE
 
@@ -259,11 +260,17 @@ class FactorAnalyser(object):
         self.Sigma = np.zeros(sv_size, dtype=STAT_TYPE)
         if tv_init is None:
             self.F = np.random.randn(sv_size, tv_rank).astype(STAT_TYPE)   # unseeded global RNG, as the reference
+            if dist.is_dist():
+                # every rank drew its own matrix: rank 0's is the one (the reference's ranks only agree from the bcast at
+                # the end of their first iteration on, sidekit_mpi.py:120-123, 241)
+                t = torch.from_numpy(self.F if dist.rank() == 0 else np.zeros_like(self.F)).to(getattr(eng, "device", "cpu"))
+                dist.allreduce_sum_(t)
+                self.F = eng.to_host(t)
         else:
             self.F = tv_init
         if output_file_name is None and always_write:
             output_file_name = "temporary_factor_analyser"
-        if save_init:
+        if save_init and dist.rank() == 0:
             self.write((output_file_name or "temporary_factor_analyser") + "_init" + self._ext())
 
         if resident is not None:
@@ -283,6 +290,7 @@ class FactorAnalyser(object):
                     self.write(output_file_name + self._ext())
 
     # ------------------------------------------------------------------ training drivers
+    @fanout
     def total_variability(self, stat_server_filename, ubm, tv_rank, nb_iter=20, min_div=True, tv_init=None,
                           batch_size=300, save_init=False, output_file_name=None, num_thread=1):
         """TV matrix EM (factor_analyser.py:535-672).  `stat_server_filename` is a StatServer file name
@@ -293,6 +301,7 @@ class FactorAnalyser(object):
         self._train(stat_server_filename, ubm, tv_rank, nb_iter, min_div, tv_init, batch_size, save_init,
                     output_file_name, always_write=True)
 
+    @fanout
     def total_variability_single(self, stat_server_filename, ubm, tv_rank, nb_iter=20, min_div=True, tv_init=None,
                                  batch_size=300, save_init=False, output_file_name=None):
         """Same arithmetic as total_variability (factor_analyser.py:430-533); files are only written when
@@ -407,6 +416,7 @@ class FactorAnalyser(object):
         e_h, sig = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=bool(uncertainty), chain=chain, T64=T64)
         return e_h, sig
 
+    @fanout
     def extract_ivectors(self, ubm, stat_server_filename, prefix='', batch_size=300, uncertainty=False,
                          num_thread=1):
         """i-vectors of every session of a StatServer file (factor_analyser.py:732-808).  Returns a

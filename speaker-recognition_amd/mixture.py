@@ -25,6 +25,7 @@ import os
 import numpy as np
 
 from . import dist
+from .team import fanout
 from . import engine as _engine
 
 
@@ -367,6 +368,7 @@ class Mixture(object):
         self._em_ref_var = _ref_var(cov - 2.0 * sh * mu + np.square(sh))   # E[(x - shift)^2] of all the frames
         return X_dev
 
+    @fanout
     def EM_split(self,
                  features_server,
                  feature_list,
@@ -390,7 +392,7 @@ class Mixture(object):
         selected = False
 
         for it in iterations[:int(np.log2(distrib_nb))]:
-            if save_partial:
+            if save_partial and dist.rank() == 0:
                 ext = ".h5" if _has_h5py() else ".npz"
                 self.write('{}_{}g{}'.format(output_file_name, self.get_distrib_nb(), ext), prefix='')
             self._split_ditribution()
@@ -422,6 +424,7 @@ class Mixture(object):
         loop.download()
         return [float(v) for v in eng.to_host(llk_dev)]
 
+    @fanout
     def EM_uniform(self, cep, distrib_nb, iteration_min=3, iteration_max=10, llk_gain=0.01, do_init=True):
         """EM from a uniform-slice start with an early stop on the gain (mixture.py:735-794)."""
         llk = []

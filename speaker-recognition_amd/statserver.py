@@ -16,6 +16,7 @@ import numpy as np
 
 from . import dist
 from . import engine as _engine
+from . import team as _team
 from .idmap import IdMap
 from .mixture import Mixture, _h5
 
@@ -207,6 +208,10 @@ class StatServer(object):
         """
         assert isinstance(ubm, Mixture), 'First parameter has to be a Mixture'
         assert hasattr(feature_server, "load"), 'Second parameter has to be a FeaturesServer'
+        team = _team._active_team()
+        if team is not None:
+            return self._accumulate_stat_team(team, ubm, feature_server, seg_indices, channel_extension, num_thread,
+                                              max_batch_frames, keep_on_device)
 
         if (seg_indices is None) \
                 or (self.stat0.shape[0] != self.segset.shape[0]) \
@@ -367,6 +372,33 @@ class StatServer(object):
 
         if dist.is_dist() and gather:
             self._gather_rows(seg_indices)
+
+    def _accumulate_stat_team(self, team, ubm, feature_server, seg_indices, channel_extension, num_thread,
+                              max_batch_frames, keep_on_device):
+        """One process, several GPUs (team.py): the host arrays are allocated once, on the caller's object, and every
+        rank thread fills ITS rows of them through its own GPU -- disjoint rows of shared arrays, so the all-gather of
+        the multi-process path has nothing to do."""
+        if (seg_indices is None) \
+                or (self.stat0.shape[0] != self.segset.shape[0]) \
+                or (self.stat1.shape[0] != self.segset.shape[0]):
+            self.stat0 = np.zeros((self.segset.shape[0], ubm.distrib_nb()), dtype=STAT_TYPE)
+            self.stat1 = np.zeros((self.segset.shape[0], ubm.sv_size()), dtype=STAT_TYPE)
+            seg_indices = range(self.segset.shape[0])
+        seg_indices = [int(i) for i in seg_indices]
+        keep = self._engine
+
+        def body(rank):
+            me = self if rank == 0 else copy.copy(self)
+            me._engine = team.engine(rank)
+            me.accumulate_stat(_team.private_copy(ubm, team, rank), _team.private_copy(feature_server, team, rank),
+                               seg_indices, channel_extension, num_thread, max_batch_frames, gather=False,
+                               keep_on_device=keep_on_device)
+        try:
+            team.run(body)
+        finally:
+            self._engine = keep
+        feature_server.keep_all_features = True
+        self.local_rows = np.asarray(seg_indices, dtype=np.int64)      # the caller's object holds every row
 
     def _gather_rows(self, seg_indices, chunk_bytes=1 << 30):
         """All-gather of the row blocks the ranks own (each rank sends ITS rows, in chunks of about chunk_bytes so
