@@ -24,10 +24,17 @@
 
 #include <stdarg.h>
 #include <stdlib.h>
+#include <string.h>
 
 // ------------------------------------------------------------------------------------------------
 // error handling
 // ------------------------------------------------------------------------------------------------
+// csrc/skm_gmm_b3.hip: the split-precision (bf16 x 3) variant of the fat E-step kernel
+size_t skm_estep_b3_wb_bytes(int CTpad);
+int skm_estep_b3_launch(SkmCtx *ctx, const float *X, long T, int D, int CTpad, int NCH, int NP, const float *wp,
+                        const float *kc, void *wb, double *slabs, double *llk_part, int nblk, int flush_tiles,
+                        hipStream_t st);
+
 static thread_local char g_err[512] = "";
 
 void skm_set_error(const char *fmt, ...)
@@ -470,6 +477,9 @@ struct Plan {
     int team_nwv;       // waves per workgroup of the Baum-Welch segment kernel (2: models of one or two component tiles)
     // single-sweep kernel (7..16 component tiles, D <= 63)
     int fused, fused_nwv, fused_blocks, fused_fat, fat_blocks;
+    // opt-in split-precision variant of the fat kernel (SKM_SPLIT=bf16x3; csrc/skm_gmm_b3.hip): 16 component tiles, 16-byte rows
+    int b3;
+    size_t off_wb;
     // wide rows (65 <= D+1 <= 160, C <= 128): the fat kernel with ONE component tile per wave, 2 or 4 waves
     int wide, wide_nwv, wide_blocks;
     size_t wide_lds;
@@ -577,6 +587,10 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         p->fused_fat = (p->fused && (fw == 2 || fw == 4) && 32 * g.D <= 2048 && (e ? atoi(e) != 0 : 1)) ? 1 : 0;
         p->fat_blocks = wgs * (fw <= 2 ? 2 : 1);
         if (p->fat_blocks > p->n_llk) p->fat_blocks = p->n_llk;
+    }
+    {
+        const char *e = getenv("SKM_SPLIT");
+        p->b3 = (p->fused_fat && g.CTpad == 16 && D % 4 == 0 && D <= 60 && e && !strcmp(e, "bf16x3")) ? 1 : 0;
     }
     p->fused_lds = ((size_t)3 * 32 * g.XS + (size_t)4 * p->fused_nwv * 32 + (size_t)p->fused_nwv * 32 +
                     (size_t)p->fused_nwv * 2 * 16 * 64) * sizeof(float);
@@ -692,6 +706,8 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
     off += 256;
     p->off_xch = off;
     off += skm_align_up((size_t)(p->team ? 8 * p->team_per_xcd * 4 * p->team_nwv * p->team_B * 64 : 0) * sizeof(float), 256);
+    p->off_wb = off;
+    off += skm_align_up(p->b3 ? skm_estep_b3_wb_bytes(g.CTpad) : 0, 256);
     p->total = off;
     return SKM_OK;
 }
@@ -947,7 +963,11 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
         // the fat kernel's first flush writes its slab; the older fused kernel adds to a cleared one
         if (!fat) SKM_HIP(hipMemsetAsync(f.slabs, 0, (size_t)nblk * nwv * 64 * nf * 32 * sizeof(double), st));
         SKM_HIP(hipMemsetAsync(f.llk_part, 0, p.n_llk * sizeof(double), st));
-        {
+        if (p.b3) {
+            if ((rc = skm_estep_b3_launch(ctx, X, T, D, p.g.CTpad, p.g.NCH, p.g.NP, wp, kc, ws + p.off_wb, f.slabs,
+                                          f.llk_part, nblk, f.flush_tiles, st)))
+                return rc;
+        } else {
             SkmProfScope ps(ctx, fat ? "k_estep_fat" : "k_estep_fused", st);
             if (fat) {
                 const int geo = ((p.tg.NP & 1) ? 2 : 0) | (p.tg.tail ? 1 : 0);

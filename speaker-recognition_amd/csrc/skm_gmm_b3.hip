@@ -1,0 +1,415 @@
+// Split-precision E-step (opt-in: SKM_SPLIT=bf16x3): the two GEMMs of k_estep_fat on the bf16 matrix cores.
+//
+// A float32 value is the exact sum of three bf16 values (8 + 8 + 8 mantissa bits).  Of the nine partial products of two
+// such sums the six largest carry everything above 2^-24 relative; v_mfma_f32_32x32x16_bf16 does sixteen k-steps in half
+// the time v_mfma_f32_32x32x2_f32 needs for two, so a float32-grade product costs 6/16 of the f32 MFMA time (the same
+// arithmetic as csrc/skm_gemm_b3.hip, which runs the two large TV products).  Everything else is k_estep_fat: one
+// 512-register wave per SIMD owns four component tiles, statistics accumulators in the 256 AGPRs behind asm MFMAs,
+// exact (max, sum) exchange between the four waves, f64 slabs.
+//
+//   logits   l[t, c] = kc[c] + sum_d x[t, d] wl[d, c] + sum_d x^2[t, d] wq[d, c]      A = frame tile, B = model
+//            K = 64 (x, zero beyond D) + 64 (x^2) = 8 k-steps of 16, 6 MFMAs each: 48 per component tile
+//   stats    acc[c, d] += sum_t gamma[t, c] [x | 1 | x^2][t, d]                        A = posteriors, B = frame tile
+//            K = the 32 frames of the tile = 2 k-steps, 4 column tiles (x 0..31, x 32..63, x^2 0..31, x^2 32..63)
+//
+// Operand fragments (lane l: r = l & 31, h = l >> 5): A holds A[row r][k = 8 h + j], B holds B[k = 8 h + j][col r],
+// j = 0..7 as eight bf16 in four registers.  The result tile is laid out as for the f32 instruction (column = lane & 31,
+// row = acc_row(register, h)), so the logits come out with frames in registers and components on lanes -- and the
+// posteriors ARE an A operand of the statistics product if k-slot (s, h, j) of that product stands for frame
+// 4 h + (j & 3) + 8 (2 s + (j >> 2)), the frame register 8 s + j of lane (c, h) holds: no cross-lane movement, the
+// frame tile is staged a second time in that k order.
+//
+// LDS per frame tile (48 KB, ring of three): LA[ks 8][plane 3][lane 64][16 B] for the logits, SB[jt 4][s 2][plane 3]
+// [lane 64][16 B] for the statistics.  The 256 threads stage a tile cooperatively, each splitting 16 + 16 values:
+// thread (frame r, h, ks) two float4 of a row for LA, thread (column d, s, h) eight frames of a column for SB.
+// The model's planes Wb[tile][ks 8][plane 3][lane 64][16 B] are made from the float32 image at the start of the call
+// (k_w_b3: the split of the SAME float32 values the f32 kernels multiply).
+#include "skm_gmm_kernels.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define B3E_TILE_BYTES 49152
+#define B3E_SB_OFF 24576
+#define B3E_NB 6
+
+struct B3EArgs {
+    const float *X;
+    long T;
+    int D;
+    const i32x4 *wb;
+    const float *kc;
+    double *slabs;
+    double *llk_part;
+    int flush_tiles;
+};
+
+__device__ __forceinline__ unsigned b3e_pk(float a, float b)
+{
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));       // v_cvt_pk_bf16_f32 (RNE)
+}
+
+// three planes of a pair of values, each plane's pair packed in one register (first value in the low half)
+__device__ __forceinline__ void b3e_split2(float a, float b, unsigned &p0, unsigned &p1, unsigned &p2)
+{
+    p0 = b3e_pk(a, b);
+    a -= __uint_as_float(p0 << 16);             // exact
+    b -= __uint_as_float(p0 & 0xffff0000u);
+    p1 = b3e_pk(a, b);
+    a -= __uint_as_float(p1 << 16);
+    b -= __uint_as_float(p1 & 0xffff0000u);
+    p2 = b3e_pk(a, b);
+}
+
+__device__ __forceinline__ void b3e_split8(const float (&v)[8], i32x4 (&pl)[3])
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned a, b, c;
+        b3e_split2(v[2 * q], v[2 * q + 1], a, b, c);
+        pl[0][q] = (int)a;
+        pl[1][q] = (int)b;
+        pl[2][q] = (int)c;
+    }
+}
+
+// the six partial products, smallest first; plane 0 is the leading term.  `s_nop 1` opens each group: an operand may
+// have been written (or copied by the compiler) by a vector instruction right in front of it.
+__device__ __forceinline__ void b3e_mm6_v(f32x16 &acc, const i32x4 (&a)[3], const i32x4 (&b)[3])
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %3, %4, %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %1, %6, %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %2, %5, %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %1, %5, %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %1, %4, %0"
+                 : "+v"(acc)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]));
+}
+__device__ __forceinline__ void b3e_mm6_a(f32x16 &acc, const i32x4 (&a)[3], const i32x4 (&b)[3])
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %3, %4, %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %1, %6, %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %2, %5, %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %1, %5, %0\n\t"
+                 "v_mfma_f32_32x32x16_bf16 %0, %1, %4, %0"
+                 : "+a"(acc)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]));
+}
+
+// 12 wait states behind the last bf16 MFMA (8 passes + 4) before a vector instruction may read a logits accumulator;
+// only the last one issued can still be in flight
+__device__ __forceinline__ void b3e_settle4(f32x16 (&lg)[4])
+{
+    asm volatile("s_nop 13" : "+v"(lg[0]), "+v"(lg[1]), "+v"(lg[2]), "+v"(lg[3]));
+}
+
+// float32 image (skm_gmm_pack / k_pack_w) -> the three bf16 planes in logits-B fragment order
+__global__ __launch_bounds__(256) void k_w_b3(const float *__restrict__ wp, int CTpad, int NCH, int NP, int D,
+                                               i32x4 *__restrict__ wb)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (tile * 8 + ks) * 64 + lane
+    if (e >= (long)CTpad * 8 * 64) return;
+    const int lane = (int)(e & 63), ks = (int)((e >> 6) & 7), tile = (int)(e >> 9);
+    const int comp = lane & 31, h = lane >> 5, kind = ks >> 2;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = 16 * (ks & 3) + 8 * h + j;
+        float x = 0.f;
+        if (d < D) {
+            int grp, ln, i;
+            if (d < 8 * NP) {
+                grp = 2 * (d >> 3) + kind;
+                ln = comp + 32 * ((d >> 2) & 1);
+                i = d & 3;
+            } else {
+                grp = NCH - 1;
+                ln = comp + 32 * kind;
+                i = d - 8 * NP;
+            }
+            x = wp[(((long)tile * NCH + grp) * 64 + ln) * 4 + i];
+        }
+        v[j] = x;
+    }
+    i32x4 pl[3];
+    b3e_split8(v, pl);
+    i32x4 *dst = wb + ((long)tile * 8 + ks) * 3 * 64 + lane;
+    dst[0] = pl[0];
+    dst[64] = pl[1];
+    dst[128] = pl[2];
+}
+
+__global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
+{
+    constexpr int NCT = 4, NF = 4, NFW = NF * 32, NWV = 4;
+    extern __shared__ __align__(16) char smem_b3[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int D = a.D;
+
+    char *ring = smem_b3;                                                        // [3][48 KB]
+    float *partm = reinterpret_cast<float *>(smem_b3 + 3 * B3E_TILE_BYTES);      // [2][NWV][32]
+    float *parts = partm + 2 * NWV * 32;                                         // [2][NWV][32]
+    float *ls = parts + 2 * NWV * 32 + wave * 32;                                // wave-private row of 32
+
+    float kcv[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) kcv[ct] = a.kc[(wave * NCT + ct) * 32 + c];
+    // this wave's model planes [ct][ks][plane][lane] behind a buffer descriptor: one per-lane offset register for every
+    // load and an immediate / scalar offset per fragment (flat addresses cost 96 address pairs, which hipcc spilled)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<i32x4 *>(a.wb + (long)(__builtin_amdgcn_readfirstlane(wave) * NCT) * 8 * 3 * 64), 0, NCT * 8 * 3 * 1024,
+        0x00027000);
+    const int wvoff = lane * 16;
+
+    f32x16 acc[NCT][NF];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int jf = 0; jf < NF; ++jf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
+
+    const long tiles = (a.T + 31) >> 5;
+    const long ta = tiles * blockIdx.x / gridDim.x, tb = tiles * (blockIdx.x + 1) / gridDim.x;
+    double *slab_lane = a.slabs + ((long)blockIdx.x * NWV + wave) * (long)(NCT * 32 * NFW) + (4 * h) * NFW + c;
+    double llk_lane = 0.0;
+
+    // ---- staging roles of this thread
+    // LA: frame ra, features 16 * wave + 8 * ha + (0..7)
+    const int ra = tid & 31, ha = (tid >> 5) & 1, da = 16 * wave + 8 * ha;
+    // SB: column db (0..63), frames 4 * hb + (j & 3) + 8 * (2 * sb + (j >> 2))
+    const int db = tid & 63, sb = (tid >> 6) & 1, hb = tid >> 7;
+    const int la_off = ((wave * 3) * 64 + ha * 32 + ra) * 16;                    // plane stride 1024, x^2: + 4 * 3 * 1024
+    const int sb_off = B3E_SB_OFF + ((((db >> 5) * 2 + sb) * 3) * 64 + hb * 32 + (db & 31)) * 16;   // x^2: + 2 * 2 * 3 * 1024
+    float pre_a[8], pre_b[8];
+    auto load_pre = [&](long t0, int nvalid) __attribute__((always_inline)) {
+        const float *row = a.X + (t0 + ra) * (long)D + da;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        if (ra < nvalid && da + 4 <= D) v0 = *reinterpret_cast<const f32x4 *>(row);
+        if (ra < nvalid && da + 8 <= D) v1 = *reinterpret_cast<const f32x4 *>(row + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pre_a[i] = v0[i];
+            pre_a[4 + i] = v1[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int fr = 4 * hb + (j & 3) + 8 * (2 * sb + (j >> 2));
+            float x = (db == D) ? 1.0f : 0.f;                                    // the ones column makes N
+            if (db < D && fr < nvalid) x = a.X[(t0 + fr) * (long)D + db];
+            pre_b[j] = x;
+        }
+    };
+    auto store_pre = [&](char *slot) __attribute__((always_inline)) {
+        i32x4 pl[3];
+        float sq[8];
+        b3e_split8(pre_a, pl);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<i32x4 *>(slot + la_off + p * 1024) = pl[p];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sq[i] = pre_a[i] * pre_a[i];
+        b3e_split8(sq, pl);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<i32x4 *>(slot + la_off + 4 * 3 * 1024 + p * 1024) = pl[p];
+        b3e_split8(pre_b, pl);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<i32x4 *>(slot + sb_off + p * 1024) = pl[p];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sq[i] = pre_b[i] * pre_b[i];
+        b3e_split8(sq, pl);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<i32x4 *>(slot + sb_off + 2 * 2 * 3 * 1024 + p * 1024) = pl[p];
+    };
+
+    if (ta < tb) {
+        const long t0 = ta << 5;
+        load_pre(t0, (int)((a.T - t0) < 32 ? (a.T - t0) : 32));
+        store_pre(ring);
+        if (ta + 1 < tb) load_pre(t0 + 32, (int)((a.T - t0 - 32) < 32 ? (a.T - t0 - 32) : 32));
+    }
+    __syncthreads();
+
+    int cur = 0;
+    f32x16 lg[NCT];
+    i32x4 wf[B3E_NB][3];
+    auto wload = [&](int item, i32x4 (&dst)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            dst[p] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   wrs, wvoff, (((item & 3) * 8 + (item >> 2)) * 3 + p) * 1024, 0));
+    };
+#pragma unroll
+    for (int i = 0; i < B3E_NB - 1; ++i) wload(i, wf[i]);
+    auto logits_start = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            float k = kcv[ct];
+            asm volatile("" : "+v"(k));             // keeps the splat inside the loop (see k_estep_fat)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lg[ct][r] = k;
+        }
+    };
+    for (long base = ta; base < tb; base += a.flush_tiles) {
+    const long end = (base + a.flush_tiles < tb) ? base + a.flush_tiles : tb;
+    logits_start();
+#pragma unroll 1
+    for (long tile = base; tile < end; ++tile) {
+        const long t0 = tile << 5;
+        const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
+        const int nxt = (cur == 2) ? 0 : cur + 1;
+        const int pslot = (int)((tile - ta) & 1);
+        const bool has_next = tile + 1 < tb;
+        const char *slot = ring + cur * B3E_TILE_BYTES;
+
+        // ---- logits: 32 items (k-step, component tile) of 6 MFMAs; the model planes stream from L2 through a ring of
+        // B3E_NB items, B3E_NB - 1 items (about a thousand cycles of MFMAs) ahead of their use; the first ones of a tile
+        // were requested in front of the previous tile's statistics product
+        {
+            const i32x4 *la = reinterpret_cast<const i32x4 *>(slot) + lane;
+            i32x4 af[3];
+#pragma unroll
+            for (int item = 0; item < 32; ++item) {
+                const int ks = item >> 2, ct = item & 3;
+                if (ct == 0) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) af[p] = la[(ks * 3 + p) * 64];
+                }
+                if (item + B3E_NB - 1 < 32) wload(item + B3E_NB - 1, wf[(item + B3E_NB - 1) % B3E_NB]);
+                __builtin_amdgcn_sched_barrier(0);
+                b3e_mm6_v(lg[ct], af, wf[item % B3E_NB]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        b3e_settle4(lg);
+
+        // ---- exact per-frame maximum over this wave's 128 components, e = 2^(l - max), per-frame sum of e
+        float m[16];
+        tile_row_max<NCT>(lg, m);
+        lane_reduce16(m, c, OpMaxHw());
+        const int frame = acc_row((c >> 1) & 15, h);
+        if ((c & 1) == 0) ls[frame] = m[0];
+        wave_lds_fence();
+        float sm[16];
+        tile_exp_sum<NCT>(lg, ls + 4 * h, sm);
+        lane_reduce16(sm, c, OpAdd());
+        if ((c & 1) == 0) {
+            partm[(pslot * NWV + wave) * 32 + frame] = m[0];
+            parts[(pslot * NWV + wave) * 32 + frame] = sm[0];
+        }
+        // next tile goes to the slot last read two tiles ago (every wave is past that tile's barrier)
+        if (has_next) store_pre(ring + nxt * B3E_TILE_BYTES);
+        __syncthreads();
+        {
+            const float *pmv = partm + pslot * NWV * 32 + c;
+            const float *psv = parts + pslot * NWV * 32 + c;
+            float mx = pmv[0];
+            for (int w = 1; w < NWV; ++w) mx = __builtin_fmaxf(mx, pmv[w * 32]);
+            float sum = 0.f;
+            for (int w = 0; w < NWV; ++w) sum += psv[w * 32] * __builtin_amdgcn_exp2f(pmv[w * 32] - mx);
+            const bool valid = c < nvalid;
+            const float f = __builtin_amdgcn_exp2f(pmv[wave * 32] - mx) * __builtin_amdgcn_rcpf(sum);
+            if (h == 0) ls[c] = valid ? f : 0.f;
+            if (wave == 0 && h == 0 && valid) llk_lane += (double)(mx + __builtin_amdgcn_logf(sum));
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 f4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                lg[ct][4 * q4 + 0] *= f4[0];
+                lg[ct][4 * q4 + 1] *= f4[1];
+                lg[ct][4 * q4 + 2] *= f4[2];
+                lg[ct][4 * q4 + 3] *= f4[3];
+            }
+        }
+        if (tile + 2 < tb) {
+            const long t2 = (tile + 2) << 5;
+            load_pre(t2, (int)((a.T - t2) < 32 ? (a.T - t2) : 32));
+        }
+
+        // ---- statistics: the posteriors' three planes (frames 8 s + j of a lane are k-slot j of k-step s), then
+        // 2 k-steps x 4 column tiles, 6 MFMAs per (component tile, column tile, k-step)
+        {
+            i32x4 gp[NCT][2][3];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = lg[ct][8 * s + j];
+                    b3e_split8(v, gp[ct][s]);
+                }
+            // the next tile's first model planes (the same every tile, but 60 registers are better used here)
+#pragma unroll
+            for (int i = 0; i < B3E_NB - 1; ++i) wload(i, wf[i]);
+            const i32x4 *sbp = reinterpret_cast<const i32x4 *>(slot + B3E_SB_OFF) + lane;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    i32x4 bf[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bf[p] = sbp[((jt * 2 + s) * 3 + p) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) b3e_mm6_a(acc[ct][jt], gp[ct][s], bf);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        logits_start();     // the next tile's; also the wait states in front of the loop's exit edge (see k_estep_fat)
+        wave_lds_fence();
+        cur = nxt;
+    }
+    if (base == ta)
+        flush_slab_agpr<NCT, NF, true>(acc, slab_lane);
+    else
+        flush_slab_agpr<NCT, NF, false>(acc, slab_lane);
+    }
+    if (ta >= tb) flush_slab_agpr<NCT, NF, true>(acc, slab_lane);   // empty range: the slab must still read as zero
+    if (wave == 0) {
+#pragma unroll
+        for (int msk = 1; msk < 32; msk <<= 1) llk_lane += __shfl_xor(llk_lane, msk);
+        if (lane == 0) a.llk_part[blockIdx.x] = llk_lane * 0.6931471805599453094;
+    }
+}
+
+size_t skm_estep_b3_lds() { return (size_t)3 * B3E_TILE_BYTES + (size_t)(4 * 4 * 32 + 4 * 32) * sizeof(float); }
+
+size_t skm_estep_b3_wb_bytes(int CTpad) { return (size_t)CTpad * 8 * 3 * 64 * 16; }
+
+// wp: the float32 image; wb: room for skm_estep_b3_wb_bytes(CTpad).  C = 512 (16 component tiles), D % 4 == 0, D <= 60.
+int skm_estep_b3_launch(SkmCtx *ctx, const float *X, long T, int D, int CTpad, int NCH, int NP, const float *wp,
+                        const float *kc, void *wb, double *slabs, double *llk_part, int nblk, int flush_tiles,
+                        hipStream_t st)
+{
+    {
+        SkmProfScope ps(ctx, "k_w_b3", st);
+        hipLaunchKernelGGL(k_w_b3, dim3((unsigned)((CTpad * 8 * 64 + 255) / 256)), dim3(256), 0, st, wp, CTpad, NCH, NP, D,
+                           static_cast<i32x4 *>(wb));
+    }
+    B3EArgs a;
+    a.X = X;
+    a.T = T;
+    a.D = D;
+    a.wb = static_cast<const i32x4 *>(wb);
+    a.kc = kc;
+    a.slabs = slabs;
+    a.llk_part = llk_part;
+    a.flush_tiles = flush_tiles;
+    const size_t lds = skm_estep_b3_lds();
+    SKM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_estep_b3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SkmProfScope ps(ctx, "k_estep_b3", st);
+    hipLaunchKernelGGL(k_estep_b3, dim3(nblk), dim3(256), lds, st, a);
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
