@@ -218,6 +218,7 @@ def main():
     ap.add_argument("--api-sessions", type=int, default=4000, help="sessions of the host-in / host-out samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs")
+    ap.add_argument("--no-split", action="store_true", help="skip the split-precision (SKM_SPLIT=bf16x3) repeat of the headline")
     ap.add_argument("--legs", default="em_split,em2048,bw,cfg1,scoring,feat,tv",
                     help="secondary legs (comma list of em_split, em2048, bw, cfg1, scoring, feat, tv)")
     ap.add_argument("--launch-check", action="store_true",
@@ -351,12 +352,14 @@ def main():
                               "algorithmic_flop_per_launch": flop_dom}
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same workload (a process
         # cannot read its own PMC counters); the committed summary is used only when the workload matches
-        pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
-        if not os.path.exists(pmc_path):
-            pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
+        for name in ("r3_pmc_hbm_traffic.json", "r3_mid_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):
+            if os.path.exists(os.path.join(ROOT, "profiles", name)):
+                pmc_path = os.path.join(ROOT, "profiles", name)
+                break
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            if pmc["workload"] == {"C": C, "D": D, "frames": T}:
+            if pmc.get("workload") == {"C": C, "D": D, "frames": T}:
                 for name, rec in pmc["kernels"].items():
                     if name.startswith(dom):
                         result["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
@@ -369,6 +372,43 @@ def main():
                                    "achieved": achp, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": achp / PEAK_F32_MFMA_TFLOPS, "algorithmic_flop_per_step": flop_path,
                                    "issued_mfma_flop_per_step": issued}
+
+    # ---- the same EM iteration with the opt-in split-precision E-step (SKM_SPLIT=bf16x3, csrc/skm_gmm_b3.hip): the two
+    # GEMMs as bf16 x 3 products on the bf16 matrix cores, float32 accumulation, float32-grade results (parity bars of
+    # tests/test_gpu_split.py).  Reported beside the headline, never as it: `value` above is the float32-MFMA path.
+    if not args.no_extra and not args.no_split:
+        note("split-precision E-step")
+        os.environ["SKM_SPLIT"] = "bf16x3"
+        try:
+            ubm_b = random_ubm(sk, C, D)
+            em_iterations(ubm_b, X, max(1, args.warmup))
+            dtb, llk_b = timed(lambda: em_iterations(ubm_b, X, args.steps), 1)
+            eng.profile(True)
+            em_iterations(ubm_b, X, nprof)
+            torch.cuda.synchronize()
+            prof_b = eng.profile_read()
+            eng.profile(False)
+        finally:
+            os.environ.pop("SKM_SPLIT", None)
+        if rank == 0:
+            kb = {k: v[1] / v[0] for k, v in prof_b.items()}
+            if "k_estep_b3" in kb:
+                achb = 8.0 * D * C * T / (kb["k_estep_b3"] * 1e-3) / 1e12
+                result["split_precision"] = {
+                    "mode": "SKM_SPLIT=bf16x3 (opt-in): x, x^2, W and the posteriors as three bf16 terms each, 6 of the 9 "
+                            "partial products on v_mfma_f32_32x32x16_bf16, float32 accumulation",
+                    "value": world * T * args.steps / dtb, "unit": "frames/s", "ms_per_step": 1e3 * dtb / args.steps,
+                    "speedup_over_headline": dt / dtb, "final_mean_llk": float(llk_b),
+                    "kernels_ms": {k: round(v, 4) for k, v in kb.items()},
+                    "kernel_algorithmic_tflops": achb,
+                    "frac_of_f32_mfma_peak": achb / PEAK_F32_MFMA_TFLOPS,
+                    "issued_bf16_mfma_tflops": 3072.0 * C * T / (kb["k_estep_b3"] * 1e-3) / 1e12,
+                    "issued_frac_of_bf16_mfma_peak": 3072.0 * C * T / (kb["k_estep_b3"] * 1e-3) / 1e12 / 2500.0,
+                    "note": "frac_of_f32_mfma_peak = algorithmic float32 flops (8 D C per frame) over the F32 MFMA peak of "
+                            "157.3 TF: above 1 is what the bf16 matrix cores buy, not a float32 roofline fraction.  The "
+                            "kernel issues 6 bf16 MFMA products per float32 product on K padded to 128 (logits) and "
+                            "128 columns (statistics): 3072 C flop per frame against the dense bf16 peak of 2.5 PF"}
+        del ubm_b
 
     # The secondary legs run on EVERY rank (weak scaling: each rank owns its sessions / frames); values are
     # whole-job aggregates over the MAX-over-ranks wall time, kernel tables are rank 0's.

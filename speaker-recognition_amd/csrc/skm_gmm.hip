@@ -590,7 +590,7 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
     }
     {
         const char *e = getenv("SKM_SPLIT");
-        p->b3 = (p->fused_fat && g.CTpad == 16 && D % 4 == 0 && D <= 60 && e && !strcmp(e, "bf16x3")) ? 1 : 0;
+        p->b3 = (p->fused_fat && g.CTpad == 16 && g.NJT == 2 && D % 4 == 0 && D <= 60 && e && !strcmp(e, "bf16x3")) ? 1 : 0;
     }
     p->fused_lds = ((size_t)3 * 32 * g.XS + (size_t)4 * p->fused_nwv * 32 + (size_t)p->fused_nwv * 32 +
                     (size_t)p->fused_nwv * 2 * 16 * 64) * sizeof(float);

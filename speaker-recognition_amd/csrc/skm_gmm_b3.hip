@@ -43,7 +43,17 @@ struct B3EArgs {
     double *slabs;
     double *llk_part;
     int flush_tiles;
+    long long *trace;     // -DB3E_TRACE builds: cycle stamps of one tile of workgroup 1, wave 0 (tools/time_b3.py)
 };
+
+#ifdef B3E_TRACE
+static long long *g_b3_trace = nullptr;
+extern "C" void skm_b3_trace_buffer(void *p) { g_b3_trace = static_cast<long long *>(p); }
+#define B3E_STAMP(k) \
+    if (trace_now) a.trace[k] = __builtin_readcyclecounter()
+#else
+#define B3E_STAMP(k)
+#endif
 
 __device__ __forceinline__ unsigned b3e_pk(float a, float b)
 {
@@ -100,6 +110,98 @@ __device__ __forceinline__ void b3e_mm6_a(f32x16 &acc, const i32x4 (&a)[3], cons
                  "v_mfma_f32_32x32x16_bf16 %0, %1, %4, %0"
                  : "+a"(acc)
                  : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]));
+}
+
+// The same six products as three statements of two, so that vector work can be placed between them: a wave issues in
+// order, an MFMA of this kind occupies the matrix pipe for 32 cycles, and the few vector instructions put behind each
+// pair run in its shadow.  `first` carries the s_nop 1 of the group.
+#define B3E_MM2(CONSTRAINT, ACC, A0, B0, A1, B1, FIRST)                                                         \
+    do {                                                                                                       \
+        if (FIRST)                                                                                             \
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\tv_mfma_f32_32x32x16_bf16 %0, %3, %4, %0" \
+                         : CONSTRAINT(ACC) : "v"(A0), "v"(B0), "v"(A1), "v"(B1));                              \
+        else                                                                                                   \
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\tv_mfma_f32_32x32x16_bf16 %0, %3, %4, %0" \
+                         : CONSTRAINT(ACC) : "v"(A0), "v"(B0), "v"(A1), "v"(B1));                              \
+    } while (0)
+
+// One MFMA per statement, with the vector work of FILL(gap) behind each: a wave issues in order, an MFMA of this kind
+// holds the matrix pipe for 32 cycles and the vector issue port for 8 of them, and single-issue instructions whose issue
+// costs sum to about 24 cycles hide in that gap (MI355X_MICROARCH.md, "single-issue instructions HIDDEN per gap").
+// Two or three 4-cycle instructions and one memory instruction per gap; packed-f32 instructions are kept out (they cost
+// ~13 cycles beside MFMAs: b3e_subf / b3e_mulf are asm so that the SLP vectoriser cannot pair them).
+#define B3E_MF(CONSTRAINT, ACC, A_, B_)                                                                          \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : CONSTRAINT(ACC) : "v"(A_), "v"(B_));               \
+    __builtin_amdgcn_sched_barrier(0)
+#define B3E_GROUP(CONSTRAINT, ACC, A, B, FILL)                                                                   \
+    do {                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        B3E_MF(CONSTRAINT, ACC, A[2], B[0]); FILL(0); __builtin_amdgcn_sched_barrier(0);                        \
+        B3E_MF(CONSTRAINT, ACC, A[0], B[2]); FILL(1); __builtin_amdgcn_sched_barrier(0);                        \
+        B3E_MF(CONSTRAINT, ACC, A[1], B[1]); FILL(2); __builtin_amdgcn_sched_barrier(0);                        \
+        B3E_MF(CONSTRAINT, ACC, A[1], B[0]); FILL(3); __builtin_amdgcn_sched_barrier(0);                        \
+        B3E_MF(CONSTRAINT, ACC, A[0], B[1]); FILL(4); __builtin_amdgcn_sched_barrier(0);                        \
+        B3E_MF(CONSTRAINT, ACC, A[0], B[0]); FILL(5); __builtin_amdgcn_sched_barrier(0);                        \
+    } while (0)
+
+__device__ __forceinline__ float b3e_subf(float a, float b)
+{
+    float d;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float b3e_mulf(float a, float b)
+{
+    float d;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// one pair of values on its way to three packed bf16 pairs, one gap of a group at a time (2, 2, 2, 1, 2, 3 instructions)
+struct B3EPairG {
+    float a, b, t0, t1;
+    unsigned p0, p1, p2;
+};
+__device__ __forceinline__ void b3e_pair_gap(B3EPairG &q, int gap)
+{
+    if (gap == 0) {
+        q.p0 = b3e_pk(q.a, q.b);
+    } else if (gap == 1) {
+        q.t0 = __uint_as_float(q.p0 << 16);
+        q.t1 = __uint_as_float(q.p0 & 0xffff0000u);
+    } else if (gap == 2) {
+        q.a = b3e_subf(q.a, q.t0);
+        q.b = b3e_subf(q.b, q.t1);
+    } else if (gap == 3) {
+        q.p1 = b3e_pk(q.a, q.b);
+    } else if (gap == 4) {
+        q.t0 = __uint_as_float(q.p1 << 16);
+        q.t1 = __uint_as_float(q.p1 & 0xffff0000u);
+    } else {
+        q.a = b3e_subf(q.a, q.t0);
+        q.b = b3e_subf(q.b, q.t1);
+        q.p2 = b3e_pk(q.a, q.b);
+    }
+}
+
+// one pair of values on its way to three packed bf16 pairs, in three steps of 4, 4 and 1 instructions
+struct B3EPair {
+    float a, b;
+    unsigned p0, p1, p2;
+};
+__device__ __forceinline__ void b3e_pair_step(B3EPair &q, int step)
+{
+    if (step == 0) {
+        q.p0 = b3e_pk(q.a, q.b);
+        q.a -= __uint_as_float(q.p0 << 16);
+        q.b -= __uint_as_float(q.p0 & 0xffff0000u);
+    } else if (step == 1) {
+        q.p1 = b3e_pk(q.a, q.b);
+        q.a -= __uint_as_float(q.p1 << 16);
+        q.b -= __uint_as_float(q.p1 & 0xffff0000u);
+    } else {
+        q.p2 = b3e_pk(q.a, q.b);
+    }
 }
 
 // 12 wait states behind the last bf16 MFMA (8 passes + 4) before a vector instruction may read a logits accumulator;
@@ -256,6 +358,9 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) lg[ct][r] = k;
         }
+        // a vector write needs two wait states before an MFMA reads the register as its C operand; the statement also
+        // keeps the splat here, where it closes the tile, instead of in front of each accumulator's first MFMA
+        asm volatile("s_nop 1" : "+v"(lg[0]), "+v"(lg[1]), "+v"(lg[2]), "+v"(lg[3]));
     };
     for (long base = ta; base < tb; base += a.flush_tiles) {
     const long end = (base + a.flush_tiles < tb) ? base + a.flush_tiles : tb;
@@ -266,28 +371,71 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
         const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
         const int nxt = (cur == 2) ? 0 : cur + 1;
         const int pslot = (int)((tile - ta) & 1);
-        const bool has_next = tile + 1 < tb;
         const char *slot = ring + cur * B3E_TILE_BYTES;
+#ifdef B3E_TRACE
+        const bool trace_now = a.trace && blockIdx.x == 1 && tid == 0 && tile - ta == 40;
+#endif
+        B3E_STAMP(0);
 
         // ---- logits: 32 items (k-step, component tile) of 6 MFMAs; the model planes stream from L2 through a ring of
         // B3E_NB items, B3E_NB - 1 items (about a thousand cycles of MFMAs) ahead of their use; the first ones of a tile
-        // were requested in front of the previous tile's statistics product
+        // were requested in front of the previous tile's statistics product.  The gaps behind the MFMAs carry: the three
+        // plane loads of item + B3E_NB - 1 (gaps 1, 3, 5); the frame planes of the next k-step (gaps 0, 2, 4 of the
+        // k-step's last item); and, in the first 16 items, the staging of the NEXT frame tile -- one pair of values
+        // split per item (16 pairs = the thread's 8 + 8 values and their squares), its three 16-byte LDS stores in gaps 0,
+        // 2, 4 of the item behind every fourth.  The staging goes to the slot last read two tiles ago (every wave is past
+        // that tile's barrier) and is harmless when there is no next tile.
         {
             const i32x4 *la = reinterpret_cast<const i32x4 *>(slot) + lane;
-            i32x4 af[3];
+            char *dst = ring + nxt * B3E_TILE_BYTES;
+            i32x4 af[2][3], pl[3], plw[3];
+            B3EPairG pr;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[0][p] = la[p * 64];
 #pragma unroll
             for (int item = 0; item < 32; ++item) {
                 const int ks = item >> 2, ct = item & 3;
-                if (ct == 0) {
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) af[p] = la[(ks * 3 + p) * 64];
+                const int grp = item >> 2, q = item & 3;         // staging: pair q of value group grp (item < 16)
+                if (item < 16) {
+                    const float u = (grp < 2) ? pre_a[2 * q] : pre_b[2 * q], v = (grp < 2) ? pre_a[2 * q + 1] : pre_b[2 * q + 1];
+                    pr.a = u;
+                    pr.b = v;
                 }
-                if (item + B3E_NB - 1 < 32) wload(item + B3E_NB - 1, wf[(item + B3E_NB - 1) % B3E_NB]);
-                __builtin_amdgcn_sched_barrier(0);
-                b3e_mm6_v(lg[ct], af, wf[item % B3E_NB]);
-                __builtin_amdgcn_sched_barrier(0);
+                const i32x4(&w)[3] = wf[item % B3E_NB];
+                const i32x4(&fa)[3] = af[ks & 1];
+                auto fill = [&](int gap) __attribute__((always_inline)) {
+                    if ((gap & 1) && item + B3E_NB - 1 < 32) {
+                        const int it2 = item + B3E_NB - 1, p = gap >> 1;
+                        wf[it2 % B3E_NB][p] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                  wrs, wvoff, (((it2 & 3) * 8 + (it2 >> 2)) * 3 + p) * 1024, 0));
+                    }
+                    if (!(gap & 1) && ct == 3 && ks < 7) af[(ks + 1) & 1][gap >> 1] = la[((ks + 1) * 3 + (gap >> 1)) * 64];
+                    if (!(gap & 1) && q == 0 && item >= 4 && item <= 16) {
+                        const int g0 = grp - 1;                  // the value group finished by the previous item
+                        const int off = (g0 < 2 ? la_off : sb_off) + ((g0 & 1) ? 12 * 1024 : 0);
+                        *reinterpret_cast<i32x4 *>(dst + off + (gap >> 1) * 1024) = plw[gap >> 1];
+                    }
+                    if (item < 16) {
+                        if (gap == 0 && (grp & 1)) {
+                            pr.a = b3e_mulf(pr.a, pr.a);
+                            pr.b = b3e_mulf(pr.b, pr.b);
+                        }
+                        b3e_pair_gap(pr, gap);
+                        if (gap == 5) {
+                            pl[0][q] = (int)pr.p0;
+                            pl[1][q] = (int)pr.p1;
+                            pl[2][q] = (int)pr.p2;
+                            if (q == 3) {
+#pragma unroll
+                                for (int p = 0; p < 3; ++p) plw[p] = pl[p];
+                            }
+                        }
+                    }
+                };
+                B3E_GROUP("+v", lg[ct], fa, w, fill);
             }
         }
+        B3E_STAMP(1);
         b3e_settle4(lg);
 
         // ---- exact per-frame maximum over this wave's 128 components, e = 2^(l - max), per-frame sum of e
@@ -304,9 +452,9 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
             partm[(pslot * NWV + wave) * 32 + frame] = m[0];
             parts[(pslot * NWV + wave) * 32 + frame] = sm[0];
         }
-        // next tile goes to the slot last read two tiles ago (every wave is past that tile's barrier)
-        if (has_next) store_pre(ring + nxt * B3E_TILE_BYTES);
+        B3E_STAMP(2);
         __syncthreads();
+        B3E_STAMP(3);
         {
             const float *pmv = partm + pslot * NWV * 32 + c;
             const float *psv = parts + pslot * NWV * 32 + c;
@@ -320,52 +468,82 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
             if (wave == 0 && h == 0 && valid) llk_lane += (double)(mx + __builtin_amdgcn_logf(sum));
         }
         wave_lds_fence();
+        float fs[16];
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             const f32x4 f4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                lg[ct][4 * q4 + 0] *= f4[0];
-                lg[ct][4 * q4 + 1] *= f4[1];
-                lg[ct][4 * q4 + 2] *= f4[2];
-                lg[ct][4 * q4 + 3] *= f4[3];
-            }
+            for (int k = 0; k < 4; ++k) fs[4 * q4 + k] = f4[k];
         }
         if (tile + 2 < tb) {
             const long t2 = (tile + 2) << 5;
             load_pre(t2, (int)((a.T - t2) < 32 ? (a.T - t2) : 32));
         }
 
-        // ---- statistics: the posteriors' three planes (frames 8 s + j of a lane are k-slot j of k-step s), then
-        // 2 k-steps x 4 column tiles, 6 MFMAs per (component tile, column tile, k-step)
+        // ---- statistics: per component tile 8 groups (k-step s, column tile jt) of 6 MFMAs.  The posteriors
+        // gamma = e * f of tile ct + 1 are scaled and split into their three planes between the MFMAs of tile ct (frames
+        // 8 s + j of a lane are k-slot j of k-step s: one pair of registers per group); tile 0 is split up front, and the
+        // groups of the last tile carry the constants the next frame tile's logits start from.
         {
-            i32x4 gp[NCT][2][3];
+            i32x4 gp[2][2][3];            // [ct & 1][k-step][plane]
+            B3EPair pr;
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = lg[ct][8 * s + j];
-                    b3e_split8(v, gp[ct][s]);
-                }
+            for (int g = 0; g < 8; ++g) {
+                pr.a = lg[0][2 * g] * fs[2 * g];
+                pr.b = lg[0][2 * g + 1] * fs[2 * g + 1];
+                b3e_pair_step(pr, 0);
+                b3e_pair_step(pr, 1);
+                b3e_pair_step(pr, 2);
+                gp[0][g >> 2][0][g & 3] = (int)pr.p0;
+                gp[0][g >> 2][1][g & 3] = (int)pr.p1;
+                gp[0][g >> 2][2][g & 3] = (int)pr.p2;
+            }
             // the next tile's first model planes (the same every tile, but 60 registers are better used here)
 #pragma unroll
             for (int i = 0; i < B3E_NB - 1; ++i) wload(i, wf[i]);
+            B3E_STAMP(4);
             const i32x4 *sbp = reinterpret_cast<const i32x4 *>(slot + B3E_SB_OFF) + lane;
+            i32x4 bf[2][3];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int p = 0; p < 3; ++p) bf[0][p] = sbp[p * 64];
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    i32x4 bf[3];
+            for (int ct = 0; ct < NCT; ++ct) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bf[p] = sbp[((jt * 2 + s) * 3 + p) * 64];
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) b3e_mm6_a(acc[ct][jt], gp[ct][s], bf);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int g = 0; g < 8; ++g) {
+                    const int sk = g >> 2, jt = g & 3, it = ct * 8 + g;
+                    B3EPairG pq;
+                    if (ct + 1 < NCT) {
+                        pq.a = lg[(ct + 1) % NCT][2 * g];
+                        pq.b = lg[(ct + 1) % NCT][2 * g + 1];
+                    }
+                    const i32x4(&ga)[3] = gp[ct & 1][sk];
+                    const i32x4(&b)[3] = bf[it & 1];
+                    auto fill = [&](int gap) __attribute__((always_inline)) {
+                        if ((gap & 1) && it + 1 < 32) {
+                            const int g1 = (g + 1) & 7;
+                            bf[(it + 1) & 1][gap >> 1] = sbp[(((g1 & 3) * 2 + (g1 >> 2)) * 3 + (gap >> 1)) * 64];
+                        }
+                        if (ct + 1 < NCT) {
+                            if (gap == 0) {
+                                pq.a = b3e_mulf(pq.a, fs[2 * g]);
+                                pq.b = b3e_mulf(pq.b, fs[2 * g + 1]);
+                            }
+                            b3e_pair_gap(pq, gap);
+                            if (gap == 5) {
+                                gp[(ct + 1) & 1][sk][0][jt] = (int)pq.p0;
+                                gp[(ct + 1) & 1][sk][1][jt] = (int)pq.p1;
+                                gp[(ct + 1) & 1][sk][2][jt] = (int)pq.p2;
+                            }
+                        }
+                    };
+                    B3E_GROUP("+a", acc[ct][jt], ga, b, fill);
                 }
+            }
         }
+        // the wait states a bf16 MFMA result needs before anything else may touch it, in front of the loop's exit edge
+        // (the compiler moves accumulators there: see k_estep_fat); the last MFMA issued wrote acc[NCT-1][NF-1]
+        asm volatile("s_nop 13" : "+a"(acc[NCT - 1][NF - 1]));
+        B3E_STAMP(5);
         logits_start();     // the next tile's; also the wait states in front of the loop's exit edge (see k_estep_fat)
         wave_lds_fence();
         cur = nxt;
@@ -406,6 +584,11 @@ int skm_estep_b3_launch(SkmCtx *ctx, const float *X, long T, int D, int CTpad, i
     a.slabs = slabs;
     a.llk_part = llk_part;
     a.flush_tiles = flush_tiles;
+#ifdef B3E_TRACE
+    a.trace = g_b3_trace;
+#else
+    a.trace = nullptr;
+#endif
     const size_t lds = skm_estep_b3_lds();
     SKM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_estep_b3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SkmProfScope ps(ctx, "k_estep_b3", st);

@@ -26,6 +26,16 @@ timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${P}_pm
 timeout -s KILL 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${P}_pmc_tv_sq -- python3 $B $TV > $O/${P}_pmc_tv_sq.log 2>&1 || exit 1
 cd "$GRAFT_REPO_ROOT"
 python tools/pmc_summary.py gpurun_out/${P}_pmc_hbm_traffic.json gpurun_out/${P}_pmc_rd gpurun_out/${P}_pmc_wr gpurun_out/${P}_pmc_sq
+python - <<PY
+import json
+p = "gpurun_out/${P}_pmc_hbm_traffic.json"
+d = json.load(open(p))
+d = {"workload": {"C": 512, "D": 60, "frames": 10000000},
+     "command": "bash tools/r3_evidence.sh ${TAG}: rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE} "
+                "--output-format csv -- python3 bench.py --no-extra --no-cpu-baseline (one pass per run), summarised by tools/pmc_summary.py",
+     **d}
+json.dump(d, open(p, "w"), indent=1)
+PY
 python tools/pmc_summary.py gpurun_out/${P}_pmc_tv.json gpurun_out/${P}_pmc_tv_rd gpurun_out/${P}_pmc_tv_wr gpurun_out/${P}_pmc_tv_sq
 find gpurun_out -name "*counter_collection.csv" -size +2M -delete
 # the trace databases are tens of MB each (gpurun merges at most 64 MiB back): keep their kernel statistics only
