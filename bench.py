@@ -353,7 +353,7 @@ def main():
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same workload (a process
         # cannot read its own PMC counters); the committed summary is used only when the workload matches
         pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
-        for name in ("r3_pmc_hbm_traffic.json", "r3_mid_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):
+        for name in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):
             if os.path.exists(os.path.join(ROOT, "profiles", name)):
                 pmc_path = os.path.join(ROOT, "profiles", name)
                 break
