@@ -259,11 +259,16 @@ class FactorAnalyser(object):
         self.mean = np.zeros(sv_size, dtype=STAT_TYPE)
         self.Sigma = np.zeros(sv_size, dtype=STAT_TYPE)
         if tv_init is None:
-            self.F = np.random.randn(sv_size, tv_rank).astype(STAT_TYPE)   # unseeded global RNG, as the reference
+            # unseeded global RNG, as the reference.  With several ranks only rank 0 draws (rank threads of one process
+            # share that RNG: a seeded run must not depend on which thread gets there first) and its matrix is the one
+            # (the reference's ranks only agree from the bcast at the end of their first iteration on,
+            # sidekit_mpi.py:120-123, 241)
+            if dist.is_dist() and dist.rank() != 0:
+                self.F = np.zeros((sv_size, tv_rank), dtype=STAT_TYPE)
+            else:
+                self.F = np.random.randn(sv_size, tv_rank).astype(STAT_TYPE)
             if dist.is_dist():
-                # every rank drew its own matrix: rank 0's is the one (the reference's ranks only agree from the bcast at
-                # the end of their first iteration on, sidekit_mpi.py:120-123, 241)
-                t = torch.from_numpy(self.F if dist.rank() == 0 else np.zeros_like(self.F)).to(getattr(eng, "device", "cpu"))
+                t = torch.from_numpy(self.F).to(getattr(eng, "device", "cpu"))
                 dist.allreduce_sum_(t)
                 self.F = eng.to_host(t)
         else:
