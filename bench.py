@@ -529,6 +529,26 @@ def main():
                               "roofline_path": {"bound": "mfma", "achieved": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12,
                                                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                                 "frac": 8.0 * D * Ce * Te / (t_k * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
+        if not args.no_split:
+            # the same iteration on the opt-in split-precision route: two sweeps of k_estep_b3 over blocks of 512 components
+            os.environ["SKM_SPLIT"] = "bf16x3"
+            try:
+                ubm_b = random_ubm(sk, Ce, D, seed=11)
+                em_iterations(ubm_b, Xe, 1)
+                eng.profile(True)
+                dtb2, _ = timed(lambda: em_iterations(ubm_b, Xe, 2), 1)
+                dtb2 /= 2
+                prof = eng.profile_read()
+                eng.profile(False)
+            finally:
+                os.environ.pop("SKM_SPLIT", None)
+            kb2 = {k: v[1] / v[0] for k, v in prof.items()}
+            if "k_b3_sweep2" in kb2:
+                result["em_c2048"]["split_precision"] = {
+                    "mode": "SKM_SPLIT=bf16x3 (opt-in): two sweeps of the split-precision kernel over blocks of 512 components",
+                    "value": args.em2048_frames / dtb2, "unit": "frames/s", "ms_per_iteration": 1e3 * dtb2,
+                    "speedup": dte / dtb2, "kernels_ms": {k: round(v, 3) for k, v in kb2.items()}}
+            del ubm_b
         del ubm_e, Xe
 
     if "cfg1" in legs:

@@ -32,8 +32,8 @@
 // csrc/skm_gmm_b3.hip: the split-precision (bf16 x 3) variant of the fat E-step kernel
 size_t skm_estep_b3_wb_bytes(int CTpad);
 int skm_estep_b3_launch(SkmCtx *ctx, const float *X, long T, int D, int CTpad, int NCH, int NP, const float *wp,
-                        const float *kc, void *wb, double *slabs, double *llk_part, int nblk, int flush_tiles,
-                        hipStream_t st);
+                        const float *kc, void *wb, double *slabs, double *llk_part, int n_llk, int nblk, int flush_tiles,
+                        int n_cb, float *pm, float *ps, float *lse, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 
@@ -479,6 +479,8 @@ struct Plan {
     int fused, fused_nwv, fused_blocks, fused_fat, fat_blocks;
     // opt-in split-precision variant of the fat kernel (SKM_SPLIT=bf16x3; csrc/skm_gmm_b3.hip): 16 component tiles, 16-byte rows
     int b3;
+    // ... and in two sweeps over blocks of 512 components above that (C = 1024, 2048, 4096, or ending inside the last block)
+    int b3two, b3_ncb, b3_blocks;
     size_t off_wb;
     // wide rows (65 <= D+1 <= 160, C <= 128): the fat kernel with ONE component tile per wave, 2 or 4 waves
     int wide, wide_nwv, wide_blocks;
@@ -590,7 +592,13 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
     }
     {
         const char *e = getenv("SKM_SPLIT");
-        p->b3 = (p->fused_fat && g.CTpad == 16 && g.NJT == 2 && D % 4 == 0 && D <= 60 && e && !strcmp(e, "bf16x3")) ? 1 : 0;
+        const bool on = e && !strcmp(e, "bf16x3");
+        p->b3 = (p->fused_fat && g.CTpad == 16 && g.NJT == 2 && D % 4 == 0 && D <= 60 && on) ? 1 : 0;
+        const int ncb = g.CTpad / 16;
+        p->b3_ncb = ncb;
+        p->b3_blocks = ncb > 0 ? (wgs / (8 * ncb)) * 8 * ncb : 0;
+        p->b3two = (with_s && on && g.CTpad % 16 == 0 && (ncb == 2 || ncb == 4 || ncb == 8) && p->b3_blocks > 0 &&
+                    g.NJT == 2 && D % 4 == 0 && D <= 60) ? 1 : 0;
     }
     p->fused_lds = ((size_t)3 * 32 * g.XS + (size_t)4 * p->fused_nwv * 32 + (size_t)p->fused_nwv * 32 +
                     (size_t)p->fused_nwv * 2 * 16 * 64) * sizeof(float);
@@ -698,6 +706,8 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
         if (p->team && slteam > sl) sl = slteam;
         const size_t slwide = (size_t)p->wide_blocks * p->wide_nwv * 32 * nf * 32 * sizeof(double);
         if (p->wide && slwide > sl) sl = slwide;
+        const size_t slb3 = (size_t)p->b3_blocks * 4 * 128 * nf * 32 * sizeof(double);
+        if (p->b3two && slb3 > sl) sl = slb3;
         off += skm_align_up(sl, 256);
     }
     p->off_flags = off;     // flags and err are cleared by one memset: keep them adjacent
@@ -707,7 +717,7 @@ static int make_plan(const SkmCtx *ctx, long T, int C, int D, bool with_s, Plan 
     p->off_xch = off;
     off += skm_align_up((size_t)(p->team ? 8 * p->team_per_xcd * 4 * p->team_nwv * p->team_B * 64 : 0) * sizeof(float), 256);
     p->off_wb = off;
-    off += skm_align_up(p->b3 ? skm_estep_b3_wb_bytes(g.CTpad) : 0, 256);
+    off += skm_align_up((p->b3 || p->b3two) ? skm_estep_b3_wb_bytes(g.CTpad) : 0, 256);
     p->total = off;
     return SKM_OK;
 }
@@ -965,7 +975,7 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
         SKM_HIP(hipMemsetAsync(f.llk_part, 0, p.n_llk * sizeof(double), st));
         if (p.b3) {
             if ((rc = skm_estep_b3_launch(ctx, X, T, D, p.g.CTpad, p.g.NCH, p.g.NP, wp, kc, ws + p.off_wb, f.slabs,
-                                          f.llk_part, nblk, f.flush_tiles, st)))
+                                          f.llk_part, p.n_llk, nblk, f.flush_tiles, 1, nullptr, nullptr, nullptr, st)))
                 return rc;
         } else {
             SkmProfScope ps(ctx, fat ? "k_estep_fat" : "k_estep_fused", st);
@@ -1006,6 +1016,24 @@ static int estep_run(SkmCtx *ctx, const Plan &p, const float *X, long T, int C, 
         SkmProfScope ps(ctx, "k_reduce_slabs", st);
         hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + SKM_RED_OUT - 1) / SKM_RED_OUT)), dim3(256), 0, st, f.slabs, nwv, nblk,
                            1, fat ? 4 : 2, p.g.NJT, nf, C, D, out, accumulate, f.llk_part, p.n_llk);
+        SKM_HIP(hipGetLastError());
+        return SKM_OK;
+    }
+    if (p.b3two && !single_sweep_only) {
+        // split precision above 512 components: two sweeps of k_estep_b3 over blocks of 512 (csrc/skm_gmm_b3.hip)
+        double *slabs = reinterpret_cast<double *>(ws + p.off_slabs);
+        double *llk_part = reinterpret_cast<double *>(ws + p.off_llk);
+        SKM_HIP(hipMemsetAsync(llk_part, 0, p.n_llk * sizeof(double), st));
+        if ((rc = skm_estep_b3_launch(ctx, X, T, D, p.g.CTpad, p.g.NCH, p.g.NP, wp, kc, ws + p.off_wb, slabs, llk_part,
+                                      p.n_llk, p.b3_blocks, skm_flush_tiles(), p.b3_ncb,
+                                      reinterpret_cast<float *>(ws + p.off_pm), reinterpret_cast<float *>(ws + p.off_ps),
+                                      reinterpret_cast<float *>(ws + p.off_lse), st)))
+            return rc;
+        const int nf = 2 * p.g.NJT;
+        const long n_out = (long)C * nf * 32;
+        SkmProfScope ps(ctx, "k_reduce_slabs", st);
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n_out + SKM_RED_OUT - 1) / SKM_RED_OUT)), dim3(256), 0, st, slabs,
+                           4 * p.b3_ncb, p.b3_blocks / p.b3_ncb, 1, 4, p.g.NJT, nf, C, D, out, accumulate, llk_part, p.n_llk);
         SKM_HIP(hipGetLastError());
         return SKM_OK;
     }

@@ -43,6 +43,10 @@ struct B3EArgs {
     double *slabs;
     double *llk_part;
     int flush_tiles;
+    // models of n_cb blocks of 512 components (MODE 1 / 2): per-(block, frame) partials out, the frames' log-sum-exp in
+    int n_cb;
+    float *pm, *ps;       // [n_cb][T] base-2 maximum and sum of 2^(l - maximum) of a block's logits
+    const float *lse;     // [T] base-2 log-sum-exp over all components (k_lse_combine)
     long long *trace;     // -DB3E_TRACE builds: cycle stamps of one tile of workgroup 1, wave 0 (tools/time_b3.py)
 };
 
@@ -247,9 +251,24 @@ __global__ __launch_bounds__(256) void k_w_b3(const float *__restrict__ wp, int 
     dst[128] = pl[2];
 }
 
-__global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
+// MODE 0: the workgroup holds every component (C <= 512): one sweep.
+// MODE 1 / 2: a model of n_cb blocks of 512 components in two sweeps over the frames (the accumulators of 2048 components
+//   do not fit one CU, and the team kernels' hand-off pipeline needs LDS this kernel spends on its bf16 planes).  Workgroup
+//   = (component block, frame range); the blocks of one frame range take workgroup ids 8 apart (one XCD: the frames come
+//   from that L2 once).  MODE 1: logits, (max, sum) of the block per frame -> pm / ps; k_lse_combine makes the frames'
+//   log-sum-exp (and the log-likelihood); MODE 2: the SAME logits again bit for bit, posteriors 2^(l - lse), statistics.
+//   2 x logits + statistics = 1.5 x the MFMA work of one sweep, at 6 / 16 of the f32 MFMA time each.
+template <int MODE>
+__global__ __launch_bounds__(256, MODE == 1 ? 2 : 1) void k_estep_b3(B3EArgs a)
 {
     constexpr int NCT = 4, NF = 4, NFW = NF * 32, NWV = 4;
+    // the first sweep stages no statistics planes and keeps no accumulators: half the LDS, under 256 registers -- two
+    // workgroups per CU, so one wave's log-sum-exp stretch runs beside the other's MFMAs
+    constexpr int TILE_BYTES = (MODE == 1) ? B3E_SB_OFF : B3E_TILE_BYTES;
+    const int n_cb = MODE ? a.n_cb : 1;
+    const int cbk = MODE ? (int)((blockIdx.x >> 3) % n_cb) : 0;
+    const int fsi = MODE ? (int)((blockIdx.x & 7) + 8 * (blockIdx.x / (8 * n_cb))) : (int)blockIdx.x;
+    const int n_fs = (int)gridDim.x / n_cb;
     extern __shared__ __align__(16) char smem_b3[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -257,17 +276,18 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
     const int D = a.D;
 
     char *ring = smem_b3;                                                        // [3][48 KB]
-    float *partm = reinterpret_cast<float *>(smem_b3 + 3 * B3E_TILE_BYTES);      // [2][NWV][32]
+    float *partm = reinterpret_cast<float *>(smem_b3 + 3 * TILE_BYTES);      // [2][NWV][32]
     float *parts = partm + 2 * NWV * 32;                                         // [2][NWV][32]
     float *ls = parts + 2 * NWV * 32 + wave * 32;                                // wave-private row of 32
 
     float kcv[NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) kcv[ct] = a.kc[(wave * NCT + ct) * 32 + c];
+    for (int ct = 0; ct < NCT; ++ct) kcv[ct] = a.kc[((cbk * NWV + wave) * NCT + ct) * 32 + c];
     // this wave's model planes [ct][ks][plane][lane] behind a buffer descriptor: one per-lane offset register for every
     // load and an immediate / scalar offset per fragment (flat addresses cost 96 address pairs, which hipcc spilled)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<i32x4 *>(a.wb + (long)(__builtin_amdgcn_readfirstlane(wave) * NCT) * 8 * 3 * 64), 0, NCT * 8 * 3 * 1024,
+        const_cast<i32x4 *>(a.wb + (long)(__builtin_amdgcn_readfirstlane(cbk * NWV + wave) * NCT) * 8 * 3 * 64), 0,
+        NCT * 8 * 3 * 1024,
         0x00027000);
     const int wvoff = lane * 16;
 
@@ -280,8 +300,9 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
             for (int r = 0; r < 16; ++r) acc[ct][jf][r] = 0.f;
 
     const long tiles = (a.T + 31) >> 5;
-    const long ta = tiles * blockIdx.x / gridDim.x, tb = tiles * (blockIdx.x + 1) / gridDim.x;
-    double *slab_lane = a.slabs + ((long)blockIdx.x * NWV + wave) * (long)(NCT * 32 * NFW) + (4 * h) * NFW + c;
+    const long ta = tiles * fsi / n_fs, tb = tiles * (fsi + 1) / n_fs;
+    // slot (frame range, block, wave) as k_reduce_slabs walks it: ((fs * (n_cb * NWV)) + cbk * NWV + wave)
+    double *slab_lane = a.slabs + ((long)fsi * (n_cb * NWV) + cbk * NWV + wave) * (long)(NCT * 32 * NFW) + (4 * h) * NFW + c;
     double llk_lane = 0.0;
 
     // ---- staging roles of this thread
@@ -302,12 +323,14 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
             pre_a[i] = v0[i];
             pre_a[4 + i] = v1[i];
         }
+        if (MODE != 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int fr = 4 * hb + (j & 3) + 8 * (2 * sb + (j >> 2));
-            float x = (db == D) ? 1.0f : 0.f;                                    // the ones column makes N
-            if (db < D && fr < nvalid) x = a.X[(t0 + fr) * (long)D + db];
-            pre_b[j] = x;
+            for (int j = 0; j < 8; ++j) {
+                const int fr = 4 * hb + (j & 3) + 8 * (2 * sb + (j >> 2));
+                float x = (db == D) ? 1.0f : 0.f;                                    // the ones column makes N
+                if (db < D && fr < nvalid) x = a.X[(t0 + fr) * (long)D + db];
+                pre_b[j] = x;
+            }
         }
     };
     auto store_pre = [&](char *slot) __attribute__((always_inline)) {
@@ -321,6 +344,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
         b3e_split8(sq, pl);
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<i32x4 *>(slot + la_off + 4 * 3 * 1024 + p * 1024) = pl[p];
+        if (MODE == 1) return;
         b3e_split8(pre_b, pl);
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<i32x4 *>(slot + sb_off + p * 1024) = pl[p];
@@ -371,11 +395,23 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
         const int nvalid = (int)((a.T - t0) < 32 ? (a.T - t0) : 32);
         const int nxt = (cur == 2) ? 0 : cur + 1;
         const int pslot = (int)((tile - ta) & 1);
-        const char *slot = ring + cur * B3E_TILE_BYTES;
+        const char *slot = ring + cur * TILE_BYTES;
 #ifdef B3E_TRACE
         const bool trace_now = a.trace && blockIdx.x == 1 && tid == 0 && tile - ta == 40;
 #endif
         B3E_STAMP(0);
+        f32x4 l4[4];
+        if (MODE == 2) {
+            // the log-sum-exp of this lane's 16 frames (register 4 q + k holds frame 8 q + 4 h + k); frames beyond T get
+            // +inf, i.e. a posterior of exactly zero (the reads themselves stay inside the workspace)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                l4[q4] = *reinterpret_cast<const f32x4 *>(a.lse + t0 + 8 * q4 + 4 * h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (8 * q4 + 4 * h + k >= nvalid) l4[q4][k] = __builtin_inff();
+            }
+        }
 
         // ---- logits: 32 items (k-step, component tile) of 6 MFMAs; the model planes stream from L2 through a ring of
         // B3E_NB items, B3E_NB - 1 items (about a thousand cycles of MFMAs) ahead of their use; the first ones of a tile
@@ -387,7 +423,8 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
         // that tile's barrier) and is harmless when there is no next tile.
         {
             const i32x4 *la = reinterpret_cast<const i32x4 *>(slot) + lane;
-            char *dst = ring + nxt * B3E_TILE_BYTES;
+            char *dst = ring + nxt * TILE_BYTES;
+            constexpr int NSTG = (MODE == 1) ? 8 : 16;      // pairs of values this thread stages (no SB planes in MODE 1)
             i32x4 af[2][3], pl[3], plw[3];
             B3EPairG pr;
 #pragma unroll
@@ -396,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
             for (int item = 0; item < 32; ++item) {
                 const int ks = item >> 2, ct = item & 3;
                 const int grp = item >> 2, q = item & 3;         // staging: pair q of value group grp (item < 16)
-                if (item < 16) {
+                if (item < NSTG) {
                     const float u = (grp < 2) ? pre_a[2 * q] : pre_b[2 * q], v = (grp < 2) ? pre_a[2 * q + 1] : pre_b[2 * q + 1];
                     pr.a = u;
                     pr.b = v;
@@ -410,12 +447,12 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
                                                                   wrs, wvoff, (((it2 & 3) * 8 + (it2 >> 2)) * 3 + p) * 1024, 0));
                     }
                     if (!(gap & 1) && ct == 3 && ks < 7) af[(ks + 1) & 1][gap >> 1] = la[((ks + 1) * 3 + (gap >> 1)) * 64];
-                    if (!(gap & 1) && q == 0 && item >= 4 && item <= 16) {
+                    if (!(gap & 1) && q == 0 && item >= 4 && item <= NSTG) {
                         const int g0 = grp - 1;                  // the value group finished by the previous item
                         const int off = (g0 < 2 ? la_off : sb_off) + ((g0 & 1) ? 12 * 1024 : 0);
                         *reinterpret_cast<i32x4 *>(dst + off + (gap >> 1) * 1024) = plw[gap >> 1];
                     }
-                    if (item < 16) {
+                    if (item < NSTG) {
                         if (gap == 0 && (grp & 1)) {
                             pr.a = b3e_mulf(pr.a, pr.a);
                             pr.b = b3e_mulf(pr.b, pr.b);
@@ -438,6 +475,19 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
         B3E_STAMP(1);
         b3e_settle4(lg);
 
+        float fs[16];
+        if (MODE == 2) {
+            // ---- posteriors from the frames' log-sum-exp: one subtraction and one exponential per logit, no exchange
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lg[ct][r] = __builtin_amdgcn_exp2f(lg[ct][r] - l4[r >> 2][r & 3]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fs[r] = 1.0f;
+            B3E_STAMP(2);
+            __syncthreads();        // ring discipline only: the staging of tile + 1 is visible, tile - 1's slot is free
+            B3E_STAMP(3);
+        } else {
         // ---- exact per-frame maximum over this wave's 128 components, e = 2^(l - max), per-frame sum of e
         float m[16];
         tile_row_max<NCT>(lg, m);
@@ -463,23 +513,34 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
             float sum = 0.f;
             for (int w = 0; w < NWV; ++w) sum += psv[w * 32] * __builtin_amdgcn_exp2f(pmv[w * 32] - mx);
             const bool valid = c < nvalid;
-            const float f = __builtin_amdgcn_exp2f(pmv[wave * 32] - mx) * __builtin_amdgcn_rcpf(sum);
-            if (h == 0) ls[c] = valid ? f : 0.f;
-            if (wave == 0 && h == 0 && valid) llk_lane += (double)(mx + __builtin_amdgcn_logf(sum));
+            if (MODE == 1) {
+                // the block's (max, sum) of frame c: all k_lse_combine needs
+                if (wave == 0 && h == 0 && valid) {
+                    a.pm[(long)cbk * a.T + t0 + c] = mx;
+                    a.ps[(long)cbk * a.T + t0 + c] = sum;
+                }
+            } else {
+                const float f = __builtin_amdgcn_exp2f(pmv[wave * 32] - mx) * __builtin_amdgcn_rcpf(sum);
+                if (h == 0) ls[c] = valid ? f : 0.f;
+                if (wave == 0 && h == 0 && valid) llk_lane += (double)(mx + __builtin_amdgcn_logf(sum));
+            }
         }
-        wave_lds_fence();
-        float fs[16];
+        if (MODE == 0) {
+            wave_lds_fence();
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 f4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 f4 = *reinterpret_cast<const f32x4 *>(ls + 8 * q4 + 4 * h);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) fs[4 * q4 + k] = f4[k];
+                for (int k = 0; k < 4; ++k) fs[4 * q4 + k] = f4[k];
+            }
+        }
         }
         if (tile + 2 < tb) {
             const long t2 = (tile + 2) << 5;
             load_pre(t2, (int)((a.T - t2) < 32 ? (a.T - t2) : 32));
         }
 
+        if (MODE != 1) {
         // ---- statistics: per component tile 8 groups (k-step s, column tile jt) of 6 MFMAs.  The posteriors
         // gamma = e * f of tile ct + 1 are scaled and split into their three planes between the MFMAs of tile ct (frames
         // 8 s + j of a lane are k-slot j of k-step s: one pair of registers per group); tile 0 is split up front, and the
@@ -543,18 +604,25 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
         // the wait states a bf16 MFMA result needs before anything else may touch it, in front of the loop's exit edge
         // (the compiler moves accumulators there: see k_estep_fat); the last MFMA issued wrote acc[NCT-1][NF-1]
         asm volatile("s_nop 13" : "+a"(acc[NCT - 1][NF - 1]));
+        } else {
+            // first sweep: no statistics; the next tile's first model planes
+#pragma unroll
+            for (int i = 0; i < B3E_NB - 1; ++i) wload(i, wf[i]);
+        }
         B3E_STAMP(5);
         logits_start();     // the next tile's; also the wait states in front of the loop's exit edge (see k_estep_fat)
         wave_lds_fence();
         cur = nxt;
     }
-    if (base == ta)
-        flush_slab_agpr<NCT, NF, true>(acc, slab_lane);
-    else
-        flush_slab_agpr<NCT, NF, false>(acc, slab_lane);
+    if (MODE != 1) {
+        if (base == ta)
+            flush_slab_agpr<NCT, NF, true>(acc, slab_lane);
+        else
+            flush_slab_agpr<NCT, NF, false>(acc, slab_lane);
     }
-    if (ta >= tb) flush_slab_agpr<NCT, NF, true>(acc, slab_lane);   // empty range: the slab must still read as zero
-    if (wave == 0) {
+    }
+    if (MODE != 1 && ta >= tb) flush_slab_agpr<NCT, NF, true>(acc, slab_lane);   // empty range: the slab must still read as zero
+    if (MODE == 0 && wave == 0) {
 #pragma unroll
         for (int msk = 1; msk < 32; msk <<= 1) llk_lane += __shfl_xor(llk_lane, msk);
         if (lane == 0) a.llk_part[blockIdx.x] = llk_lane * 0.6931471805599453094;
@@ -562,16 +630,20 @@ __global__ __launch_bounds__(256, 1) void k_estep_b3(B3EArgs a)
 }
 
 size_t skm_estep_b3_lds() { return (size_t)3 * B3E_TILE_BYTES + (size_t)(4 * 4 * 32 + 4 * 32) * sizeof(float); }
+static size_t skm_estep_b3_lds_sweep1() { return (size_t)3 * B3E_SB_OFF + (size_t)(4 * 4 * 32 + 4 * 32) * sizeof(float); }
 
 size_t skm_estep_b3_wb_bytes(int CTpad) { return (size_t)CTpad * 8 * 3 * 64 * 16; }
 
-// wp: the float32 image; wb: room for skm_estep_b3_wb_bytes(CTpad).  C = 512 (16 component tiles), D % 4 == 0, D <= 60.
+// wp: the float32 image; wb: room for skm_estep_b3_wb_bytes(CTpad).  D % 4 == 0, 32 <= D <= 60.
+// n_cb == 1: C <= 512 (16 component tiles), one sweep, nblk workgroups (llk_part gets one partial per workgroup).
+// n_cb  > 1: CTpad = 16 n_cb tiles in two sweeps; nblk must be a multiple of 8 n_cb; pm / ps: n_cb * T floats each, lse: T
+//            floats (+ 32 readable beyond), llk_part: n_llk partials written by k_lse_combine.
 int skm_estep_b3_launch(SkmCtx *ctx, const float *X, long T, int D, int CTpad, int NCH, int NP, const float *wp,
-                        const float *kc, void *wb, double *slabs, double *llk_part, int nblk, int flush_tiles,
-                        hipStream_t st)
+                        const float *kc, void *wb, double *slabs, double *llk_part, int n_llk, int nblk, int flush_tiles,
+                        int n_cb, float *pm, float *ps, float *lse, hipStream_t st)
 {
     {
-        SkmProfScope ps(ctx, "k_w_b3", st);
+        SkmProfScope ps_(ctx, "k_w_b3", st);
         hipLaunchKernelGGL(k_w_b3, dim3((unsigned)((CTpad * 8 * 64 + 255) / 256)), dim3(256), 0, st, wp, CTpad, NCH, NP, D,
                            static_cast<i32x4 *>(wb));
     }
@@ -584,15 +656,47 @@ int skm_estep_b3_launch(SkmCtx *ctx, const float *X, long T, int D, int CTpad, i
     a.slabs = slabs;
     a.llk_part = llk_part;
     a.flush_tiles = flush_tiles;
+    a.n_cb = n_cb;
+    a.pm = pm;
+    a.ps = ps;
+    a.lse = lse;
 #ifdef B3E_TRACE
     a.trace = g_b3_trace;
 #else
     a.trace = nullptr;
 #endif
     const size_t lds = skm_estep_b3_lds();
-    SKM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_estep_b3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SkmProfScope ps(ctx, "k_estep_b3", st);
-    hipLaunchKernelGGL(k_estep_b3, dim3(nblk), dim3(256), lds, st, a);
+    if (n_cb <= 1) {
+        SKM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_estep_b3<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        SkmProfScope ps_(ctx, "k_estep_b3", st);
+        hipLaunchKernelGGL(k_estep_b3<0>, dim3(nblk), dim3(256), lds, st, a);
+        SKM_HIP(hipGetLastError());
+        return SKM_OK;
+    }
+    SKM_REQUIRE(nblk % (8 * n_cb) == 0 && pm && ps && lse, "split-precision E-step in two sweeps: bad launch geometry");
+    const size_t lds1 = skm_estep_b3_lds_sweep1();
+    SKM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_estep_b3<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds1));
+    SKM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_estep_b3<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    {
+        SkmProfScope ps_(ctx, "k_b3_sweep1", st);
+        hipLaunchKernelGGL(k_estep_b3<1>, dim3(2 * nblk), dim3(256), lds1, st, a);      // two workgroups per CU
+    }
+    SKM_HIP(hipGetLastError());
+    long nb = (T + 255) / 256;
+    if (nb > n_llk) nb = n_llk;
+    if (nb < 1) nb = 1;
+    {
+        SkmProfScope ps_(ctx, "k_lse_combine", st);
+        hipLaunchKernelGGL(k_lse_combine, dim3((unsigned)nb), dim3(256), 0, st, pm, ps, n_cb, T, lse, (float *)nullptr, llk_part);
+    }
+    SKM_HIP(hipGetLastError());
+    {
+        SkmProfScope ps_(ctx, "k_b3_sweep2", st);
+        hipLaunchKernelGGL(k_estep_b3<2>, dim3(nblk), dim3(256), lds, st, a);
+    }
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }

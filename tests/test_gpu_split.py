@@ -79,6 +79,31 @@ def test_split_estep_vs_oracle(eng, split, C, D, T, flush):
     assert rel(out[:C], ref[:C]) < 5e-5 and rel(out[C:-1], ref[C:-1]) < 5e-5
 
 
+@pytest.mark.parametrize("C,D,T", [(1024, 60, 9999), (2048, 60, 6000), (2048, 36, 95), (2000, 60, 7000), (4096, 60, 4100),
+                                   (1024, 44, 1), (2048, 60, 300000)])
+def test_split_two_sweeps_vs_oracle(eng, split, C, D, T):
+    """Above 512 components the split route takes two sweeps over blocks of 512 (the second repeats the first one's logits
+    bit for bit, so the posteriors of a frame sum to one to float32 rounding of one log-sum-exp)."""
+    gmm = orc.random_gmm(C, D, seed=C + D)
+    cep = orc.synth_frames(T, dim=D, clusters=16, seed=T)
+    X = eng.upload_frames(cep)
+    packed = eng.pack_stats(gmm.w, gmm.mu, gmm.invcov)
+    out = eng.to_host(eng.estep(X, packed))
+    prof = _which(eng, X, packed)
+    assert "k_b3_sweep1" in prof and "k_b3_sweep2" in prof, prof
+    assert np.array_equal(out, eng.to_host(eng.estep(X, packed)))
+    N, F, S, llk = unpack(out, C, D)
+    rN, rF, rS, rl = orc.expectation(gmm, cep.astype(np.float64))
+    assert rel(N, rN) < TOL and rel(F, rF) < TOL and rel(S, rS) < TOL
+    rows = (rel_rows(N, rN), rel_rows(S, rS), rel_rownorm(S, rS))
+    assert max(rows) < TOL, rows
+    check_first_order(F, rF)
+    assert abs(llk - rl) < 1e-5 * abs(rl)
+    assert abs(N.sum() - T) < 2e-6 * T + 1e-3          # posteriors sum to one per frame, well below the logit's own error
+    acc = eng.estep(X, packed, out=eng.estep(X, packed), accumulate=True)
+    assert rel(eng.to_host(acc), 2.0 * out) < 1e-12
+
+
 def test_split_estep_vs_reference_golden(eng, split):
     """The reference's own numbers (tests/golden/estep_c64_d60.npz holds 64 components: padded here to the 512 the split
     kernel is built for by repeating the model 8 times with an eighth of the weight -- N, F, S of a copy are an eighth)."""

@@ -10,7 +10,7 @@ import sidekit_amd as sk
 from bench import synth_frames_device, random_ubm
 from conftest import rel, rel_rows, rel_rownorm
 
-C, D = 512, int(os.environ.get("D", 60))
+C, D = int(os.environ.get("C", 512)), int(os.environ.get("D", 60))
 eng = sk.default_engine()
 ubm = random_ubm(sk, C, D)
 packed = eng.pack_stats(ubm.w, ubm.mu, ubm.invcov) if os.environ.get("REF", "1") == "1" else eng.pack(ubm.w, ubm.mu, ubm.invcov)
