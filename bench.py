@@ -441,6 +441,20 @@ def main():
                               "final_mean_llk": float(llk_s[-1]),
                               "kernels_ms": {k: round(v[1], 2) for k, v in sorted(prof.items())},
                               "path_frac_of_mfma_peak": flop / dts / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        if not args.no_split:
+            # the same call with the opt-in split-precision E-step: the last stage (512 components, 8 of the 37 iterations)
+            # runs on k_estep_b3, the stages below it on the same kernels as above
+            os.environ["SKM_SPLIT"] = "bf16x3"
+            try:
+                sk.Mixture().EM_split(fs_all, ["all"], distrib_nb=C)
+                ubm_sb = sk.Mixture()
+                dtsb, llk_sb = timed(lambda: ubm_sb.EM_split(fs_all, ["all"], distrib_nb=C), 1)
+            finally:
+                os.environ.pop("SKM_SPLIT", None)
+            result["em_split"]["split_precision"] = {"seconds": dtsb, "speedup": dts / dtsb,
+                                                     "final_mean_llk": float(llk_sb[-1]),
+                                                     "mode": "SKM_SPLIT=bf16x3 (opt-in): the 512-component stage on k_estep_b3"}
+            del ubm_sb
         del fs_all, ubm_s
 
     if "bw" in legs:
