@@ -16,10 +16,12 @@
 // dense N dimension) is applied by the split of B and by the epilogue's store.
 //
 // Kernel: workgroup = 8 waves = 256 x 256 tile (wave: 128 x 64 = 4 x 2 MFMA blocks, 128 accumulator registers), BK = 16
-// (one MFMA k-step) per stage, two LDS stages of 48 KB, global -> registers -> LDS one stage ahead, one barrier per
-// stage; one workgroup per CU, two waves per SIMD.  Per stage and wave: 18 ds_read_b128, 48 MFMAs.  The tile is this
-// large because the operands cost 6 bytes per element and the loads come from L2: the first version (128 x 128 tiles)
-// pulled 8 TB/s out of the L2s and stopped there, at 0.43 of the bf16 MFMA rate.
+// (one MFMA k-step) per stage, a ring of three LDS stages of 48 KB filled by LDS-direct loads two stages ahead of the
+// one being multiplied (round 3: the first version staged through registers ONE stage ahead and waited for its loads
+// at the end of every stage), one barrier per stage; one workgroup per CU, two waves per SIMD.  Per stage and wave:
+// 6 buffer_load ... lds, 18 ds_read_b128, 48 MFMAs.  The tile is this large because the operands cost 6 bytes per
+// element and the loads come from L2: the first version (128 x 128 tiles) pulled 8 TB/s out of the L2s and stopped
+// there, at 0.43 of the bf16 MFMA rate.
 #include "skm_gemm.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -27,6 +29,13 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define B3_TILE 256
 #define B3_BK 16
+#define B3_STAGES 3
+// the wait that retires a stage's LDS-direct loads (tests/test_isa_lint.py builds this file without it: lint rule iii)
+#ifdef SKM_LINT_DEMO_B3_NO_DMA_WAIT
+#define B3_WAIT_LOADS ""
+#else
+#define B3_WAIT_LOADS "s_waitcnt vmcnt(6)\n\t"
+#endif
 
 __device__ __forceinline__ unsigned b3_bf16_rn(float x)
 {
@@ -111,8 +120,8 @@ struct B3Args {
 template <typename TO>
 __global__ __launch_bounds__(512, 1) void k_gemm_b3(B3Args g)
 {
-    // [stage][operand A/B][plane][k-group of the stage][row]
-    __shared__ i32x4 sh[2][2][3][B3_BK / 8][B3_TILE];
+    // [stage][operand A/B][plane][k-group of the stage][row]: a ring of three 48 KB stages
+    __shared__ i32x4 sh[B3_STAGES][2][3][B3_BK / 8][B3_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, r = lane & 31, h = lane >> 5;      // wave tile: rows wm*128.., cols wn*64..
     // XCD-aware order: workgroups w, w + 8, ... share an XCD; one XCD walks the M tiles of ONE N tile column back to
@@ -123,13 +132,30 @@ __global__ __launch_bounds__(512, 1) void k_gemm_b3(B3Args g)
     if (tn >= g.tiles_n) return;
     const long m0 = (long)tm * B3_TILE, n0 = (long)tn * B3_TILE;
 
-    // staging: plane p = i, k-group of the stage = tid >> 8, row = tid & 255
-    const int skg = tid >> 8, srow = tid & 255;
+    // Staging: the stages go from L2 straight into LDS (buffer_load ... lds, 16 bytes per lane: one instruction of a
+    // wave fills 64 consecutive rows of one k-group of one plane = 1 KB of the stage), two stages ahead of the one
+    // being multiplied: no staging registers, no LDS stores, and a load has two stages' worth of MFMAs (~2.5 us) to
+    // arrive.  Wave w stages k-group w >> 2, rows 64 (w & 3) .. + 63 of every plane of both operands: 6 loads per stage.
+    // One descriptor per plane, based at this tile's first row; the stage advances in the scalar offset.
+    const int skg = wave >> 2, srow0 = (wave & 3) * 64;
     const long plA = g.KG * g.Mp, plB = g.KG * g.Np;
-    const i32x4 *ga = g.A + (long)skg * g.Mp + m0 + srow;
-    const i32x4 *gb = g.B + (long)skg * g.Np + n0 + srow;
-    const long stepA = (long)(B3_BK / 8) * g.Mp, stepB = (long)(B3_BK / 8) * g.Np;
+    __amdgpu_buffer_rsrc_t rsa[3], rsb[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        rsa[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<i32x4 *>(g.A + p * plA + m0), 0,
+                                                   (int)(unsigned)((plA - m0) * 16), 0x00027000);
+        rsb[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<i32x4 *>(g.B + p * plB + n0), 0,
+                                                   (int)(unsigned)((plB - n0) * 16), 0x00027000);
+    }
+    const int voa = (int)(((long)skg * g.Mp + srow0 + lane) * 16), vob = (int)(((long)skg * g.Np + srow0 + lane) * 16);
+    const int stepA = (int)((long)(B3_BK / 8) * g.Mp * 16), stepB = (int)((long)(B3_BK / 8) * g.Np * 16);   // bytes per stage
     const int nk = (int)(g.KG / (B3_BK / 8));
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+#define B3_ISSUE(S, ST)                                                                                              \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa[p], (lds_ptr)&sh[ST][0][p][skg][srow0], 16, voa, (S) * stepA, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb[p], (lds_ptr)&sh[ST][1][p][skg][srow0], 16, vob, (S) * stepB, 0, 0); \
+    }
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -139,63 +165,118 @@ __global__ __launch_bounds__(512, 1) void k_gemm_b3(B3Args g)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
 
-    i32x4 ra[3], rb[3];
-#define B3_FETCH(S)                                                          \
-    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                           \
-        ra[p] = ga[p * plA + (long)(S) * stepA];                             \
-        rb[p] = gb[p * plB + (long)(S) * stepB];                             \
-    }
-#define B3_PUT(ST)                                                           \
-    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                           \
-        sh[ST][0][p][skg][srow] = ra[p];                                     \
-        sh[ST][1][p][skg][srow] = rb[p];                                     \
-    }
 #define B3_MM(PA, PB)                                                                                         \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)         \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][mi], fb[PB][ni], acc[mi][ni], 0, 0, 0);
-    B3_FETCH(0)
-    B3_PUT(0)
-    if (nk > 1) { B3_FETCH(1) }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        bf16x8 fa[3][4], fb[3][2];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) fa[p][b] = __builtin_bit_cast(bf16x8, sh[cur][0][p][h][wm * 128 + b * 32 + r]);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) fb[p][b] = __builtin_bit_cast(bf16x8, sh[cur][1][p][h][wn * 64 + b * 32 + r]);
-        }
-        // six products per block, smallest terms first; consecutive MFMAs go to different accumulators
-        B3_MM(2, 0) B3_MM(0, 2) B3_MM(1, 1) B3_MM(1, 0) B3_MM(0, 1) B3_MM(0, 0)
-        // stage kt + 1 (requested one stage ago) goes to the other LDS buffer behind this stage's MFMAs
-        if (kt + 1 < nk) { B3_PUT(cur ^ 1) }
-        if (kt + 2 < nk) { B3_FETCH(kt + 2) }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // Two wave groups (waves 0-3 and 4-7: one wave of each per SIMD) run the same program ONE BARRIER APART.  A stage
+    // is two phases, each closed by a barrier: R = issue the loads of stage kt + 2, read the 18 fragments of stage kt;
+    // M = the 48 MFMAs.  While one group multiplies, the other reads: the LDS reads (and their latency behind the
+    // barrier) of one wave sit under the MFMAs of the other wave of the SIMD, instead of both waves reading, then both
+    // multiplying.  Global phase 2 kt: group 0 in R(kt), group 1 in M(kt - 1); phase 2 kt + 1: group 0 in M(kt),
+    // group 1 in R(kt).
+    //   visibility of stage kt + 1 (first read: group 0's R(kt + 1), global phase 2 kt + 2): every wave waits for its own
+    //   pieces in front of the barrier that closes global phase 2 kt + 1 -- group 0 at the end of M(kt), group 1 at the
+    //   end of R(kt); the six loads of stage kt + 2, issued in R(kt), stay in flight across it.
+    //   reuse of a slot: stage kt + 2 goes where stage kt - 1 was; its last readers (group 1, R(kt - 1), global phase
+    //   2 kt - 1) retire their reads (lgkmcnt(0)) in front of the barrier that closes that phase, and the earliest
+    //   issue of the loads is group 0's R(kt), global phase 2 kt.
+    // Every iteration issues exactly six loads (behind the last stage the last stage again, into the free slot), so the
+    // wait is the same vmcnt(6) everywhere; the loop is written once per group, without a branch on the group inside.
+    const int wg = wave >> 2;
+    B3_ISSUE(0, 0)
+    B3_ISSUE(nk > 1 ? 1 : 0, 1)
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+#define B3_READ_FRAGMENTS()                                                                                          \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                   \
+        _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                                 \
+            fa[p][b] = __builtin_bit_cast(bf16x8, sh[cur][0][p][h][wm * 128 + b * 32 + r]);                           \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                 \
+            fb[p][b] = __builtin_bit_cast(bf16x8, sh[cur][1][p][h][wn * 64 + b * 32 + r]);                            \
     }
+    // six products per block, smallest terms first; consecutive MFMAs go to different accumulators
+#define B3_PRODUCTS() B3_MM(2, 0) B3_MM(0, 2) B3_MM(1, 1) B3_MM(1, 0) B3_MM(0, 1) B3_MM(0, 0)
+#define B3_ADVANCE()                                                                                                 \
+    cur = (cur == B3_STAGES - 1) ? 0 : cur + 1;                                                                      \
+    nxt = (nxt == B3_STAGES - 1) ? 0 : nxt + 1;
+    int cur = 0, nxt = 2;       // ring slots of stage kt and of stage kt + 2
+    bf16x8 fa[3][4], fb[3][2];
+    if (wg == 0) {
+        for (int kt = 0; kt < nk; ++kt) {
+            B3_ISSUE(kt + 2 < nk ? kt + 2 : nk - 1, nxt)                                    // phase R
+            B3_READ_FRAGMENTS()
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            B3_PRODUCTS()                                                                   // phase M
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile(B3_WAIT_LOADS "s_barrier" ::: "memory");                           // stage kt + 1 has landed
+            __builtin_amdgcn_sched_barrier(0);
+            B3_ADVANCE()
+        }
+    } else {
+        asm volatile("s_barrier" ::: "memory");                                             // one phase behind
+        for (int kt = 0; kt < nk; ++kt) {
+            B3_ISSUE(kt + 2 < nk ? kt + 2 : nk - 1, nxt)                                    // phase R
+            B3_READ_FRAGMENTS()
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile(B3_WAIT_LOADS "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage kt + 1 has landed
+            __builtin_amdgcn_sched_barrier(0);
+            B3_PRODUCTS()                                                                   // phase M
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) asm volatile("s_barrier" ::: "memory");                        // the last phase has no partner
+            __builtin_amdgcn_sched_barrier(0);
+            B3_ADVANCE()
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-issued last stage: nothing lands in LDS behind the exit
+#undef B3_ADVANCE
+#undef B3_PRODUCTS
+#undef B3_READ_FRAGMENTS
 #undef B3_MM
-#undef B3_PUT
-#undef B3_FETCH
+#undef B3_ISSUE
 
+    // Epilogue.  Accumulating onto C reads the 16 old values of a 32 x 32 block with 16 loads in flight (rows and
+    // columns beyond the matrix are clamped to its last ones for the load and masked for the store): with the load
+    // inside the bounds test hipcc waited for every single one (128 round trips to HBM per wave, a quarter of the A
+    // accumulation's time).
     TO *C = static_cast<TO *>(g.C);
+    long colv[2];
+    bool okn[2];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int ni = 0; ni < 2; ++ni) {
+        const long gn = n0 + wn * 64 + ni * 32 + r;
+        okn[ni] = gn < g.N;
+        const long gc = okn[ni] ? gn : g.N - 1;
+        colv[ni] = g.colmap ? (long)g.colmap[gc] : gc;
+    }
+    if (g.accumulate) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const long gn = n0 + wn * 64 + ni * 32 + r;
-            if (gn >= g.N) continue;
-            const long col = g.colmap ? (long)g.colmap[gn] : gn;
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const long gm = m0 + wm * 128 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (gm < g.M) {
-                    TO *p = C + gm * g.ldc + col;
-                    const TO v = (TO)acc[mi][ni][q];
-                    *p = g.accumulate ? (TO)(*p + v) : v;
+            for (int ni = 0; ni < 2; ++ni) {
+                TO old[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const long gm = m0 + wm * 128 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    old[q] = C[(gm < g.M ? gm : g.M - 1) * g.ldc + colv[ni]];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const long gm = m0 + wm * 128 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    if (okn[ni] && gm < g.M) C[gm * g.ldc + colv[ni]] = (TO)(old[q] + (TO)acc[mi][ni][q]);
                 }
             }
-        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const long gm = m0 + wm * 128 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    if (okn[ni] && gm < g.M) C[gm * g.ldc + colv[ni]] = (TO)acc[mi][ni][q];
+                }
+    }
 }
 
 int skm_b3_gemm(SkmCtx *ctx, const void *Ap, long M, const void *Bp, long N, long K, void *C, int c_f64, long ldc,
@@ -218,6 +299,9 @@ int skm_b3_gemm(SkmCtx *ctx, const void *Ap, long M, const void *Bp, long N, lon
     g.tiles_n = (int)(g.Np / B3_TILE);
     const long grid = (long)((g.tiles_n + 7) / 8 * 8) * g.tiles_m;
     SKM_REQUIRE(grid < 0x7FFFFFFFL, "b3_gemm(%s): grid too large", tag);
+    // one buffer descriptor per plane: 32-bit extents and offsets
+    SKM_REQUIRE(g.KG * g.Mp * 16 < 0xFFFFFFFFL && g.KG * g.Np * 16 < 0xFFFFFFFFL,
+                "b3_gemm(%s): a plane of an operand exceeds 4 GB (M=%ld N=%ld K=%ld)", tag, M, N, K);
     SkmProfScope ps(ctx, tag, st);
     if (c_f64)
         hipLaunchKernelGGL(k_gemm_b3<double>, dim3((unsigned)grid), dim3(512), 0, st, g);

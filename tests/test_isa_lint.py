@@ -77,3 +77,17 @@ def test_lint_is_red_with_a_wait_removed(tmp_path, macro, rule):
         assert lines and all(line.startswith(rule) for line in lines), lines[:4]
         if macro == "SKM_LINT_DEMO_ODD_NO_SETTLE":      # round 2's wrong-logits bug, in the kernel that had it
             assert any("k_estep_solo" in isa_lint.demangle(name) for name, _ in findings)
+
+
+@needs_tools
+def test_lint_is_red_without_the_ring_wait_of_the_split_gemm(tmp_path):
+    """csrc/skm_gemm_b3.hip keeps its LDS-direct loads in flight for two iterations (RING_DEPTH in the lint): built
+    without the vmcnt(6) that retires a stage, rule (iii) must name every one of its loads."""
+    obj = str(tmp_path / "b3.o")
+    src = os.path.join(ROOT, "speaker-recognition_amd", "csrc", "skm_gemm_b3.hip")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                    "-DSKM_LINT_DEMO_B3_NO_DMA_WAIT", "-c", src, "-o", obj], check=True, cwd=str(tmp_path))
+    findings = isa_lint.lint_file(obj)
+    lines = [line for name, f in findings for line in f if "k_gemm_b3" in name]
+    assert lines and all(line.startswith("(iii)") for line in lines), lines[:4]
+    assert all("k_gemm_b3" in name for name, _ in findings)

@@ -16,6 +16,8 @@ and checks, per kernel, linearly over the instruction stream:
   (iii) LDS-direct loads.  `buffer_load ... lds` whose data a `ds_read` of the NEXT loop iteration (or, outside a loop,
         any later `ds_read`) can reach before an `s_waitcnt vmcnt(n)` that covers the load: hipcc emits no such wait
         for this load kind.  (A `ds_read` in the SAME iteration belongs to the other buffer of the ring by design.)
+        Kernels listed in RING_DEPTH keep their loads in flight longer -- a ring of three LDS stages filled two
+        iterations ahead: there the reads of the iteration after next are the ones that must be covered.
 
 A wait state is one issued instruction; `s_nop n` counts n + 1.  One refinement over LLVM's counting (which is one per
 instruction whatever it is): the matrix pipe takes one MFMA at a time, so a second MFMA of the same kind issues no
@@ -56,6 +58,10 @@ MFMA_PASSES = [
     (re.compile(r"^v_mfma_f32_32x32x16_"), 8),
 ]
 STRICT = False
+# LDS-direct loads: iterations between a load and the first ds_read of its data (default 1: a ring of two buffers)
+RING_DEPTH = [
+    (re.compile(r"k_gemm_b3"), 2),      # csrc/skm_gemm_b3.hip: three stages, loads issued two stages ahead, vmcnt(6)
+]
 REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])(?![\w\[])")
 LINE = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
 LABEL = re.compile(r"^[0-9a-f]+ <(.+)>:")
@@ -329,7 +335,11 @@ def lint_kernel(name, ins):
                             if any(overlap(r, d) for d in dsts):
                                 found.append("(ii)  %s @%x writes %s%d, %s @%x reads it after %d of 2 wait states"
                                              % (a.op, a.addr, r[0], r[1], b.op, b.addr, since))
-    # ---- (iii) LDS-direct loads against the ds_reads of the next iteration
+    # ---- (iii) LDS-direct loads against the ds_reads of the next iteration (of the iteration `depth` later)
+    depth = 1
+    for pat, d in RING_DEPTH:
+        if pat.search(name):
+            depth = d
     for i, a in enumerate(ins):
         if not a.lds_direct:
             continue
@@ -339,7 +349,7 @@ def lint_kernel(name, ins):
             continue                                        # not in a loop
         # state (instruction, crossed a back edge of a loop that holds the load) -> fewest vector-memory
         # instructions issued behind the load on any path there (the fewest is the worst case for a vmcnt(n))
-        best, stack, bad = {}, [(t, False, 0) for t in succ[i]], None
+        best, stack, bad = {}, [(t, 0, 0) for t in succ[i]], None
         while stack and bad is None:
             j, wrapped, later = stack.pop()
             if best.get((j, wrapped), 1 << 30) <= later:
@@ -350,17 +360,19 @@ def lint_kernel(name, ins):
                 m = re.search(r"vmcnt\((\d+)\)", b.args)
                 if m and int(m.group(1)) <= later:
                     continue                                # this path is covered
-            if wrapped and (b.op.startswith("ds_read") or b.op.startswith("ds_load")):
+            if wrapped >= depth and (b.op.startswith("ds_read") or b.op.startswith("ds_load")):
                 bad = b
                 break
-            if j == i and wrapped:
-                continue
+            if j == i and wrapped > depth:
+                continue                                    # the whole iteration that reads the data has been walked
             nxt = later + (1 if b.vmem else 0)
             for t in succ[j]:
-                stack.append((t, wrapped or (j, t) in back, nxt))
+                stack.append((t, min(depth + 1, wrapped + (1 if (j, t) in back else 0)), nxt))
         if bad is not None:
-            found.append("(iii) %s @%x (LDS-direct): %s @%x of the next loop iteration is reachable before an "
-                         "s_waitcnt vmcnt that covers the load" % (a.op, a.addr, bad.op, bad.addr))
+            found.append("(iii) %s @%x (LDS-direct): %s @%x of the %s is reachable before an "
+                         "s_waitcnt vmcnt that covers the load"
+                         % (a.op, a.addr, bad.op, bad.addr,
+                            "next loop iteration" if depth == 1 else "loop iteration %d later" % depth))
     return found
 
 
