@@ -410,7 +410,10 @@ np.savez(sys.argv[1], **out)
         np.testing.assert_array_equal(res["0"][k], res["1"][k], err_msg=k)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (300, 517, 100), (1000, 777, 2048), (64, 4096, 333), (2049, 130, 4096)])
+# K = 1 .. 49 walks the three-stage ring of the kernel through 1, 2, 3 and 4 stages (its start-up and its wrap-around)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (300, 517, 100), (1000, 777, 2048), (64, 4096, 333), (2049, 130, 4096),
+                                   (5, 7, 1), (256, 256, 16), (257, 300, 17), (100, 513, 33), (64, 64, 48), (300, 300, 49),
+                                   (512, 512, 64), (40, 1000, 100), (513, 40, 1000)])
 def test_split_gemm_is_a_float32_product(eng, M, N, K):
     """skm_gemm_split (three bf16 terms per operand, six bf16 MFMA products, float32 accumulation) against the float64
     product of the same float32 operands: as close as the float32 MFMA GEMM is -- the split loses nothing that
@@ -426,12 +429,14 @@ def test_split_gemm_is_a_float32_product(eng, M, N, K):
     f32 = eng.to_host(eng.gemm(Ad, Bd)).astype(np.float64)
     e_split = (np.abs(got - ref) / scale).max()
     e_f32 = (np.abs(f32 - ref) / scale).max()
-    assert e_split < 1.25 * e_f32 + 1e-8 and e_split < 4e-6, (e_split, e_f32)
+    # 1.5e-7 = 2.5 x 2^-24: what the split owes by itself on a sum of one or two terms (three dropped partial products
+    # of <= 2^-26 each and the float32 rounding of the sum), where the f32 MFMA returns the correctly rounded product
+    assert e_split < max(1.25 * e_f32 + 1e-8, 1.5e-7) and e_split < 4e-6, (e_split, e_f32)
     # float64 output, accumulated onto an existing C
     C0 = rs.randn(M, N)
     Cd = torch.from_numpy(C0.copy()).to(eng.device)
     eng.gemm_split(Ad, Bd, C=Cd)
-    assert (np.abs(eng.to_host(Cd) - (C0 + ref)) / (scale + np.abs(C0))).max() < 1.25 * e_f32 + 1e-8
+    assert (np.abs(eng.to_host(Cd) - (C0 + ref)) / (scale + np.abs(C0))).max() < max(1.25 * e_f32 + 1e-8, 1.5e-7)
 
 
 @pytest.mark.timeout(600)
