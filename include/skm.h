@@ -264,6 +264,19 @@ int skm_tv_estep(void *ctx, const float *naug_dev, const float *ftilde_dev, long
                  double *e_h_dev, double *iv_sigma_dev, int chain, const double *T64_dev, void *ws_dev,
                  size_t ws_bytes, void *stream);
 
+/* The same E-step with the two products that read f~ -- aux = f~ T (sidekit/factor_analyser.py:88) and
+ * C += e_h' f~ (:125) -- on the bf16 matrix cores as well (three-term split operands, see skm_gemm_split): f~ is a
+ * constant of the whole training run, so its planes are built ONCE by skm_tv_ftilde_planes (12 bytes per element:
+ * one image with k = supervector index for the aux product, one with k = session for the C accumulation;
+ * skm_tv_ftilde_planes_bytes(S, C, D) bytes) and handed to every iteration.  ft_planes_dev = NULL, SKM_TV_SPLIT=0 or
+ * SKM_TV_PRECISE: exactly skm_tv_estep.  The C accumulation takes the planes only when batch is a multiple of 16. */
+size_t skm_tv_ftilde_planes_bytes(long S, int C, int D);
+int skm_tv_ftilde_planes(void *ctx, const float *ftilde_dev, long S, int C, int D, void *planes_dev, void *stream);
+int skm_tv_estep_planes(void *ctx, const float *naug_dev, const float *ftilde_dev, const void *ft_planes_dev, long S,
+                        int C, int D, int R, const float *T32_dev, const float *G_dev, int batch, double *A_aug_dev,
+                        double *Cacc_dev, double *e_h_dev, double *iv_sigma_dev, int chain, const double *T64_dev,
+                        void *ws_dev, size_t ws_bytes, void *stream);
+
 /* TV M-step: F_out_dev[C*D*R] = per component (A_c^-1 C_c)'; A_aug rows 0..C-1 are destroyed.
  * Replaces the solve loop of factor_analyser.py:653-658 (the reference's LU solve of the SPD system is
  * done by a blocked Cholesky inverse).  Minimum divergence (:661-665) = skm_gemm with chol(R). */

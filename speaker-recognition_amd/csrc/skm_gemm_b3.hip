@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void k_b3_split(const float *__restrict__ src,
 
 static inline long b3_pad(long v, long a) { return (v + a - 1) / a * a; }
 
+long skm_b3_rows_padded(long rows) { return b3_pad(rows, B3_TILE); }
+long skm_b3_kgroups(long K) { return b3_pad(K, B3_BK) / 8; }
+
 size_t skm_b3_plane_bytes(long rows, long K)
 {
     return (size_t)3 * (size_t)(b3_pad(K, B3_BK) / 8) * (size_t)b3_pad(rows, B3_TILE) * 16;
@@ -109,12 +112,15 @@ int skm_b3_split(SkmCtx *ctx, const float *src, long rows, long K, long ld, int 
 struct B3Args {
     const i32x4 *A, *B;       // planes[3][KG][Mp or Np] of 16-byte k-groups
     long Mp, Np, KG;          // padded rows / columns, k-groups of 8 (KG * 8 = padded K, a multiple of B3_BK)
+    long plA, plB;            // distance between the planes of an operand (16-byte units): KG * Mp / KG * Np unless the
+                              // product runs over a k range of larger planes
     long M, N;
     void *C;
     long ldc;
     const int *colmap;
     int accumulate;
     int tiles_m, tiles_n;
+    int swap;                 // XCD-aware tile order: 0 = an XCD walks the M tiles of one N tile, 1 = the N tiles of one M tile
 };
 
 template <typename TO>
@@ -126,10 +132,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_b3(B3Args g)
     const int wm = wave >> 2, wn = wave & 3, r = lane & 31, h = lane >> 5;      // wave tile: rows wm*128.., cols wn*64..
     // XCD-aware order: workgroups w, w + 8, ... share an XCD; one XCD walks the M tiles of ONE N tile column back to
     // back, so the (large) B tile of the column is fetched into that XCD's L2 once
-    const int bx = blockIdx.x, fast = g.tiles_m;
+    // (with fewer N tiles than M tiles -- the aux product of the TV path has two -- the roles are swapped: an XCD walks
+    // the N tiles of one M tile)
+    const int bx = blockIdx.x, fast = g.swap ? g.tiles_n : g.tiles_m;
     const int grp = bx / (8 * fast), rr = bx % (8 * fast);
-    const int tn = grp * 8 + (rr & 7), tm = rr >> 3;
-    if (tn >= g.tiles_n) return;
+    const int slow_i = grp * 8 + (rr & 7), fast_i = rr >> 3;
+    const int tn = g.swap ? fast_i : slow_i, tm = g.swap ? slow_i : fast_i;
+    if (tn >= g.tiles_n || tm >= g.tiles_m) return;
     const long m0 = (long)tm * B3_TILE, n0 = (long)tn * B3_TILE;
 
     // Staging: the stages go from L2 straight into LDS (buffer_load ... lds, 16 bytes per lane: one instruction of a
@@ -138,14 +147,15 @@ __global__ __launch_bounds__(512, 1) void k_gemm_b3(B3Args g)
     // arrive.  Wave w stages k-group w >> 2, rows 64 (w & 3) .. + 63 of every plane of both operands: 6 loads per stage.
     // One descriptor per plane, based at this tile's first row; the stage advances in the scalar offset.
     const int skg = wave >> 2, srow0 = (wave & 3) * 64;
-    const long plA = g.KG * g.Mp, plB = g.KG * g.Np;
+    const long plA = g.plA, plB = g.plB;
+    const long extA = g.KG * g.Mp, extB = g.KG * g.Np;        // what this product reads of a plane
     __amdgpu_buffer_rsrc_t rsa[3], rsb[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         rsa[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<i32x4 *>(g.A + p * plA + m0), 0,
-                                                   (int)(unsigned)((plA - m0) * 16), 0x00027000);
+                                                   (int)(unsigned)((extA - m0) * 16), 0x00027000);
         rsb[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<i32x4 *>(g.B + p * plB + n0), 0,
-                                                   (int)(unsigned)((plB - n0) * 16), 0x00027000);
+                                                   (int)(unsigned)((extB - n0) * 16), 0x00027000);
     }
     const int voa = (int)(((long)skg * g.Mp + srow0 + lane) * 16), vob = (int)(((long)skg * g.Np + srow0 + lane) * 16);
     const int stepA = (int)((long)(B3_BK / 8) * g.Mp * 16), stepB = (int)((long)(B3_BK / 8) * g.Np * 16);   // bytes per stage
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_b3(B3Args g)
 }
 
 int skm_b3_gemm(SkmCtx *ctx, const void *Ap, long M, const void *Bp, long N, long K, void *C, int c_f64, long ldc,
-                const int *colmap, int accumulate, hipStream_t st, const char *tag)
+                const int *colmap, int accumulate, hipStream_t st, const char *tag, long plane_a, long plane_b)
 {
     SKM_REQUIRE(ctx && Ap && Bp && C && M > 0 && N > 0 && K > 0, "b3_gemm(%s): bad argument", tag);
     B3Args g;
@@ -289,6 +299,8 @@ int skm_b3_gemm(SkmCtx *ctx, const void *Ap, long M, const void *Bp, long N, lon
     g.Mp = b3_pad(M, B3_TILE);
     g.Np = b3_pad(N, B3_TILE);
     g.KG = b3_pad(K, B3_BK) / 8;
+    g.plA = plane_a ? plane_a : g.KG * g.Mp;
+    g.plB = plane_b ? plane_b : g.KG * g.Np;
     g.M = M;
     g.N = N;
     g.C = C;
@@ -297,7 +309,8 @@ int skm_b3_gemm(SkmCtx *ctx, const void *Ap, long M, const void *Bp, long N, lon
     g.accumulate = accumulate;
     g.tiles_m = (int)(g.Mp / B3_TILE);
     g.tiles_n = (int)(g.Np / B3_TILE);
-    const long grid = (long)((g.tiles_n + 7) / 8 * 8) * g.tiles_m;
+    g.swap = g.tiles_n < g.tiles_m;
+    const long grid = g.swap ? (long)((g.tiles_m + 7) / 8 * 8) * g.tiles_n : (long)((g.tiles_n + 7) / 8 * 8) * g.tiles_m;
     SKM_REQUIRE(grid < 0x7FFFFFFFL, "b3_gemm(%s): grid too large", tag);
     // one buffer descriptor per plane: 32-bit extents and offsets
     SKM_REQUIRE(g.KG * g.Mp * 16 < 0xFFFFFFFFL && g.KG * g.Np * 16 < 0xFFFFFFFFL,

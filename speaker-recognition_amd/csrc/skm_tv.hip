@@ -398,6 +398,7 @@ static int blocked_inverse(SkmCtx *ctx, T *Mb, T *out, T *Tb, int nb, int R, int
 struct TvWs {
     size_t off_mb, off_linv, off_e, off_tb, off_aux, off_eh32, off_map, off_cs, off_auxs, off_y, total;
     size_t off_gs, off_ns, off_nt, off_es;      // bf16 x 3 planes of G, of the batch's N (both orientations) and of e_hh
+    size_t off_tp, off_ep;                      // planes of the loading matrix (aux product) and of a batch's e_h' (C accumulation)
     size_t off_g64, off_f64, off_n64;           // SKM_TV_PRECISE: float64 Gram matrices, f~ rows and N of a chunk
     int ksplit;
 };
@@ -475,7 +476,7 @@ static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0, int D = 0, 
         w.off_n64 = off;
         off += skm_align_up((size_t)batch * tv_ldn(C) * sizeof(double), 256);
     }
-    w.off_gs = w.off_ns = w.off_nt = w.off_es = 0;
+    w.off_gs = w.off_ns = w.off_nt = w.off_es = w.off_tp = w.off_ep = 0;
     if (S > 0 && C > 0 && tv_split()) {
         const long NT = tv_tri_cols(R);
         w.off_gs = off;
@@ -486,6 +487,10 @@ static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0, int D = 0, 
         off += skm_align_up(skm_b3_plane_bytes(C, batch), 256);
         w.off_es = off;
         off += skm_align_up(skm_b3_plane_bytes(NT, batch), 256);
+        w.off_tp = off;
+        off += skm_align_up(skm_b3_plane_bytes(R, (long)C * D), 256);
+        w.off_ep = off;
+        off += skm_align_up(skm_b3_plane_bytes(R, batch), 256);
     }
     w.total = off;
     return w;
@@ -672,9 +677,35 @@ extern "C" int skm_tv_prepare(void *ctx_, const double *T, int C, int D, int R, 
     return skm_gemm_launch(ctx, SKM_GEMM_F64_F32OUT, g, C, st, "k_gemm_gram");
 }
 
-extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, long S, int C, int D, int R,
-                            const float *T32, const float *G, int batch, double *A_aug, double *Cacc, double *e_h,
-                            double *iv_sigma, int chain, const double *T64, void *ws_, size_t ws_bytes, void *stream)
+// Planes of f~ for skm_tv_estep_planes: [ rows image: sessions x (k = supervector) | columns image: supervector x (k = sessions) ]
+static size_t tv_ft_rows_bytes(long S, int C, int D) { return skm_align_up(skm_b3_plane_bytes(S, (long)C * D), 256); }
+
+extern "C" size_t skm_tv_ftilde_planes_bytes(long S, int C, int D)
+{
+    if (S <= 0 || C <= 0 || D <= 0) return 0;
+    return tv_ft_rows_bytes(S, C, D) + skm_align_up(skm_b3_plane_bytes((long)C * D, S), 256);
+}
+
+extern "C" int skm_tv_ftilde_planes(void *ctx_, const float *ftilde, long S, int C, int D, void *planes, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && ftilde && planes, "skm_tv_ftilde_planes: NULL argument");
+    SKM_REQUIRE(S > 0 && C > 0 && D > 0, "skm_tv_ftilde_planes: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const long CD = (long)C * D;
+    char *p = static_cast<char *>(planes);
+    int rc;
+    if ((rc = skm_b3_split(ctx, ftilde, S, CD, CD, 1, nullptr, p, st, "k_b3_split_f"))) return rc;
+    return skm_b3_split(ctx, ftilde, CD, S, CD, 0, nullptr, p + tv_ft_rows_bytes(S, C, D), st, "k_b3_split_f");
+}
+
+// k per float32 accumulation run of the aux product on the split GEMM (float64 across runs, in the output)
+#define TV_AUX_CHUNK_B3 4096
+
+static int tv_estep_impl(void *ctx_, const float *naug, const float *ftilde, long S, int C, int D, int R,
+                         const float *T32, const float *G, int batch, double *A_aug, double *Cacc, double *e_h,
+                         double *iv_sigma, int chain, const double *T64, void *ws_, size_t ws_bytes, void *stream,
+                         const void *ft_planes)
 {
     SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
     SKM_REQUIRE(ctx && naug && ftilde && T32 && G && e_h && ws_, "skm_tv_estep: NULL argument");
@@ -731,6 +762,19 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
             SKM_HIP(hipGetLastError());
             GemmArgs g = skm_gemm_args(f64, T64, aux + r0 * R, (int)nr, R, (int)CD, CD, R, R);
             if ((rc = skm_gemm_launch(ctx, SKM_GEMM_F64_F64, g, 1, st, "k_gemm_aux"))) return rc;
+        }
+    } else if (ft_planes && w.off_tp) {
+        // f~ was split once for the whole training run (skm_tv_ftilde_planes): the aux product on the bf16 matrix
+        // cores, float32 sums over runs of TV_AUX_CHUNK_B3 k, float64 across the runs in the output
+        void *Tp = ws + w.off_tp;
+        if ((rc = skm_b3_split(ctx, T32, R, CD, R, 0, nullptr, Tp, st, "k_b3_split"))) return rc;
+        const long Sp = skm_b3_rows_padded(S), Rp = skm_b3_rows_padded(R), KGt = skm_b3_kgroups(CD);
+        const char *fa = static_cast<const char *>(ft_planes);
+        for (long k0 = 0; k0 < CD; k0 += TV_AUX_CHUNK_B3) {
+            const long kn = (CD - k0) < TV_AUX_CHUNK_B3 ? (CD - k0) : TV_AUX_CHUNK_B3;
+            if ((rc = skm_b3_gemm(ctx, fa + (k0 / 8) * Sp * 16, S, static_cast<const char *>(Tp) + (k0 / 8) * Rp * 16, R, kn,
+                                  aux, 1, R, nullptr, k0 ? 1 : 0, st, "k_gemm_aux", KGt * Sp, KGt * Rp)))
+                return rc;
         }
     } else if (w.ksplit > 1) {
         double *slabs = reinterpret_cast<double *>(ws + w.off_auxs);
@@ -821,8 +865,20 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         // C += e_h' f~ (factor_analyser.py:125), one product per batch like the A accumulation: float32 MFMA sums over
         // the <= `batch` sessions of a batch, float64 across batches (the plain k-loop with BK = 32 is 10 % faster here
         // than one float64-folding product over all sessions)
+        const bool cacc_planes = ft_planes && w.off_ep && !precise && batch % 16 == 0;
         for (long b0 = 0; b0 < S; b0 += batch) {
             const int nb = (int)((S - b0) < batch ? (S - b0) : batch);
+            if (cacc_planes) {
+                // e_h' of the batch split (k = session), f~ from the columns image at the batch's k range
+                void *Ep = ws + w.off_ep;
+                if ((rc = skm_b3_split(ctx, eh32 + b0 * R, R, nb, R, 0, nullptr, Ep, st, "k_b3_split"))) return rc;
+                const long CDp = skm_b3_rows_padded(CD), KGs = skm_b3_kgroups(S);
+                const char *fc = static_cast<const char *>(ft_planes) + tv_ft_rows_bytes(S, C, D);
+                if ((rc = skm_b3_gemm(ctx, Ep, R, fc + (b0 / 8) * CDp * 16, CD, nb, Cacc, 1, CD, nullptr, 1, st, "k_gemm_cacc",
+                                      0, KGs * CDp)))
+                    return rc;
+                continue;
+            }
             GemmArgs c = skm_gemm_args(eh32 + b0 * R, ftilde + b0 * CD, Cacc, R, (int)CD, nb, R, CD, CD);
             c.transA = 1;
             c.beta = 1.0;
@@ -831,6 +887,23 @@ extern "C" int skm_tv_estep(void *ctx_, const float *naug, const float *ftilde, 
         }
     }
     return SKM_OK;
+}
+
+extern "C" int skm_tv_estep(void *ctx, const float *naug, const float *ftilde, long S, int C, int D, int R,
+                            const float *T32, const float *G, int batch, double *A_aug, double *Cacc, double *e_h,
+                            double *iv_sigma, int chain, const double *T64, void *ws, size_t ws_bytes, void *stream)
+{
+    return tv_estep_impl(ctx, naug, ftilde, S, C, D, R, T32, G, batch, A_aug, Cacc, e_h, iv_sigma, chain, T64, ws, ws_bytes,
+                         stream, nullptr);
+}
+
+extern "C" int skm_tv_estep_planes(void *ctx, const float *naug, const float *ftilde, const void *ft_planes, long S, int C,
+                                   int D, int R, const float *T32, const float *G, int batch, double *A_aug, double *Cacc,
+                                   double *e_h, double *iv_sigma, int chain, const double *T64, void *ws, size_t ws_bytes,
+                                   void *stream)
+{
+    return tv_estep_impl(ctx, naug, ftilde, S, C, D, R, T32, G, batch, A_aug, Cacc, e_h, iv_sigma, chain, T64, ws, ws_bytes,
+                         stream, ft_planes);
 }
 
 // M-step: T_c = (A_c^-1 C_c)' for every component; A_aug rows 0..C-1 are destroyed.

@@ -76,6 +76,11 @@ SIGNATURES = {
     "skm_tv_estep": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p,
                               _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                               _c_void_p, _c_size_t, _c_void_p]),
+    "skm_tv_ftilde_planes_bytes": (_c_size_t, [_c_long, _c_int, _c_int]),
+    "skm_tv_ftilde_planes": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "skm_tv_estep_planes": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p,
+                                     _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
+                                     _c_void_p, _c_size_t, _c_void_p]),
     "skm_tv_mstep": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p,
                               _c_void_p, _c_size_t, _c_void_p]),
     "skm_moments_workspace_bytes": (_c_size_t, [_c_void_p, _c_int]),
@@ -808,12 +813,30 @@ class HipEngine(object):
 
     TV_CHAIN = {None: 0, "default": 0, "f32": 1, "f64": 2, "precise": 3}
 
+    def tv_ftilde_planes(self, ft, C, D):
+        """The bf16 x 3 planes of f~ (skm_tv_ftilde_planes): built once per training run and handed to every
+        tv_estep(..., ft_planes=...), which then runs aux = f~ T and C += e_h' f~ on the bf16 matrix cores too.
+        12 bytes per element of f~; None when SKM_TV_FT_PLANES=0 or when they would not fit beside what is resident."""
+        import os
+        if os.environ.get("SKM_TV_FT_PLANES", "1") == "0" or os.environ.get("SKM_TV_SPLIT", "1") == "0":
+            return None
+        S = ft.shape[0]
+        need = int(self.lib.skm_tv_ftilde_planes_bytes(S, C, D))
+        free, _total = self.torch.cuda.mem_get_info(self.device)
+        if need == 0 or need > 0.6 * free:
+            return None
+        planes = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
+        self._check(self.lib.skm_tv_ftilde_planes(self.ctx, _c_void_p(ft.data_ptr()), S, C, D,
+                                                  _c_void_p(planes.data_ptr()), self._stream()))
+        return planes
+
     def tv_estep(self, naug, ft, T32, G, C, D, batch=1024, A_aug=None, Cacc=None, uncertainty=False, chain=None,
-                 T64=None):
+                 T64=None, ft_planes=None):
         """E-step over the sessions of (naug, ft).  Returns (e_h, iv_sigma or None); when A_aug/Cacc are
         given (training) the accumulators are updated in place.  chain: "f32" / "f64" = type of the per-session
         Cholesky / inverse chain (None: float32 unless SKM_TV_CHAIN says otherwise); "precise" (with T64, the float64
-        loading matrix on the device) = everything e_h depends on in float64, for long sessions / large loadings."""
+        loading matrix on the device) = everything e_h depends on in float64, for long sessions / large loadings.
+        ft_planes: what tv_ftilde_planes(ft, C, D) returned, or None."""
         torch = self.torch
         S = naug.shape[0]
         R = T32.shape[1]
@@ -826,7 +849,10 @@ class HipEngine(object):
         need = self.lib.skm_tv_workspace_bytes(self.ctx, C, D, R, S, batch, self.TV_CHAIN[chain])
         ws = self.workspace(need)
         null = _c_void_p(None)
-        self._check(self.lib.skm_tv_estep(self.ctx, _c_void_p(naug.data_ptr()), _c_void_p(ft.data_ptr()), S, C, D, R,
+        if ft_planes is not None:
+            assert ft_planes.numel() == self.lib.skm_tv_ftilde_planes_bytes(S, C, D), "ft_planes of another shape"
+        self._check(self.lib.skm_tv_estep_planes(self.ctx, _c_void_p(naug.data_ptr()), _c_void_p(ft.data_ptr()),
+                                          _c_void_p(ft_planes.data_ptr()) if ft_planes is not None else null, S, C, D, R,
                                           _c_void_p(T32.data_ptr()), _c_void_p(G.data_ptr()), batch,
                                           _c_void_p(A_aug.data_ptr()) if A_aug is not None else null,
                                           _c_void_p(Cacc.data_ptr()) if Cacc is not None else null,

@@ -206,8 +206,9 @@ class FactorAnalyser(object):
             return "precise", T_dev
         return (mode if mode in ("f32", "f64") else None), None
 
-    def _tv_iteration(self, ft, naug, T_dev, C, D, R, total_sessions, min_div, batch):
-        """One EM iteration on the device; returns the new loading matrix (device, float64)."""
+    def _tv_iteration(self, ft, naug, T_dev, C, D, R, total_sessions, min_div, batch, ft_planes=None):
+        """One EM iteration on the device; returns the new loading matrix (device, float64).  ft_planes: the
+        three-term bf16 planes of ft (engine.tv_ftilde_planes), built once per training run, or None."""
         eng = self.engine
         torch = eng.torch
         T32, G = eng.tv_prepare(T_dev, C, D)
@@ -215,7 +216,8 @@ class FactorAnalyser(object):
         Cacc = torch.zeros((R, C * D), dtype=torch.float64, device=eng.device)
         chain, T64 = self._estep_chain(T_dev, naug, C, D)
         if ft is not None:
-            eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, A_aug=A_aug, Cacc=Cacc, chain=chain, T64=T64)
+            more = {"ft_planes": ft_planes} if ft_planes is not None else {}
+            eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, A_aug=A_aug, Cacc=Cacc, chain=chain, T64=T64, **more)
         del G
         world = dist.world_size()
         sharded = dist.is_dist() and C % world == 0
@@ -285,8 +287,13 @@ class FactorAnalyser(object):
         batch = 4096   # device batch (14 GB of scratch at R = 400): results do not depend on it, the reference
                        # batches only to bound host memory; 4096 measured 2.5 % faster than 2048, 9 % faster than 1024
         T_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(self.F, dtype=np.float64))).to(eng.device)
+        # f~ does not change over the iterations: split it once for the two products that read it (about the time one
+        # iteration saves, so from two iterations on; 12 bytes per element, skipped when that does not fit)
+        planes = None
+        if nb_iter >= 2 and ft is not None and hasattr(eng, "tv_ftilde_planes"):
+            planes = eng.tv_ftilde_planes(ft, C, D)
         for it in range(nb_iter):
-            T_dev = self._tv_iteration(ft, naug, T_dev, C, D, tv_rank, total, min_div, batch)
+            T_dev = self._tv_iteration(ft, naug, T_dev, C, D, tv_rank, total, min_div, batch, ft_planes=planes)
             self.F = eng.to_host(T_dev)
             if output_file_name is not None and dist.rank() == 0:
                 if it < nb_iter - 1:

@@ -165,6 +165,45 @@ def test_estep_accumulators_and_mstep(eng, case):
     assert rel(Fn, rF) < 1e-4
 
 
+def test_estep_with_ftilde_planes(eng):
+    """skm_tv_estep_planes: aux = f~ T and C += e_h' f~ from the three-term bf16 planes of f~ (built once per training
+    run) against the plain route -- which the tests above pin to the oracle -- at float32 rounding of the two products,
+    and the i-vectors of 16 sessions against the oracle itself.  Shape: C D = 5120 (two k runs of the aux product), 700
+    sessions in batches of 256 (three batches, the last one ragged: 188 sessions, not a multiple of 16)."""
+    C, D, R, S, batch = 128, 40, 96, 700, 256
+    gmm = orc.random_gmm(C, D, seed=43)
+    rs = np.random.RandomState(12)
+    post = rs.dirichlet(np.full(C, 0.4), size=S)
+    s0 = (rs.randint(300, 3000, size=(S, 1)) * post).astype(np.float32)
+    n_rep = np.repeat(s0.astype(np.float64), D, axis=1)
+    s1 = (n_rep * gmm.mu.flatten() + np.sqrt(n_rep) / np.sqrt(gmm.invcov.flatten()) * rs.randn(S, C * D)).astype(np.float32)
+    Fm = 0.1 * rs.randn(C * D, R)
+    torch = eng.torch
+    ft, naug = eng.tv_whiten(dev(eng, s0), dev(eng, s1), gmm.mu.flatten(), gmm.invcov.flatten())
+    planes = eng.tv_ftilde_planes(ft, C, D)
+    assert planes is not None
+    T32, G = eng.tv_prepare(dev(eng, Fm), C, D)
+    out = {}
+    for name, more in (("plain", {}), ("planes", {"ft_planes": planes})):
+        A_aug = torch.zeros((C + 1, R * R), dtype=torch.float64, device=eng.device)
+        Cacc = torch.zeros((R, C * D), dtype=torch.float64, device=eng.device)
+        e_h, sig = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, A_aug=A_aug, Cacc=Cacc, uncertainty=True, **more)
+        out[name] = (eng.to_host(A_aug).reshape(C + 1, R, R), eng.to_host(Cacc), eng.to_host(e_h), eng.to_host(sig))
+    for k, what in enumerate(("A", "C", "e_h", "sigma")):
+        assert np.isfinite(out["planes"][k]).all(), what
+        assert rel(out["planes"][k], out["plain"][k]) < (5e-6 if what == "sigma" else 2e-6), what    # sigma has e_h squared
+    assert rel_rows(out["planes"][1], out["plain"][1]) < 1e-4          # C accumulation, element-wise per row
+    assert min_cosine(out["planes"][2], out["plain"][2]) > 1.0 - 1e-9
+    # an independent float64 check of the C accumulation from the i-vectors of the planes route
+    c64 = eng.to_host(dev(eng, out["planes"][2]).T @ ft.double())
+    assert rel(out["planes"][1], c64) < 2e-6
+    iv, _ = orc.extract_ivectors(s0[:16], s1[:16], gmm, Fm)
+    assert rel(out["planes"][2][:16], iv) < 2e-5 and min_cosine(out["planes"][2][:16], iv) > 0.9999
+    # extraction (no accumulators) through the planes route
+    e_s, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, ft_planes=planes)
+    assert rel(eng.to_host(e_s)[:16], iv) < 2e-5
+
+
 def test_total_variability_dropin_vs_reference_golden(sk, tmp_path):
     g = golden("tv.npz")
     ubm = _ubm(sk, g)
