@@ -59,19 +59,43 @@ __device__ __forceinline__ void b3_split(float x, unsigned &b1, unsigned &b2, un
 __global__ __launch_bounds__(256) void k_b3_split(const float *__restrict__ src, long rows, long K, long ld, int kfast,
                                                   const int *__restrict__ rowmap, i32x4 *__restrict__ dst, long Rp, long KG)
 {
-    const long total = Rp * KG;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long kg = i / Rp, row = i - kg * Rp;
+    // thread -> (row, k-group).  A k-fast source is walked so that four neighbouring threads read the 128 contiguous bytes
+    // of one row (k-groups 4 q .. 4 q + 3) and threads four apart take consecutive rows: whole cache lines on the way
+    // in, 256-byte runs per k-group on the way out (one thread per row and k-group with the rows fastest used 32 bytes
+    // of every line it fetched: 4 x the reads).  A row-fast source has the rows fastest on both sides.
+    const long total = Rp * KG, KQ = (KG + 3) / 4, walk = kfast ? Rp * KQ * 4 : total;
+    const bool vec = kfast && (ld & 3) == 0 && ((uintptr_t)src & 15) == 0;       // 16-byte loads along k
+    for (long w = (long)blockIdx.x * blockDim.x + threadIdx.x; w < walk; w += (long)gridDim.x * blockDim.x) {
+        long kg, row;
+        if (kfast) {
+            const long q = w / (Rp * 4), rem = w - q * (Rp * 4);
+            row = rem >> 2;
+            kg = q * 4 + (rem & 3);
+            if (kg >= KG) continue;
+        } else {
+            kg = w / Rp;
+            row = w - kg * Rp;
+        }
+        const long i = kg * Rp + row;
         unsigned t1[8], t2[8], t3[8];
         long off = 0;
         if (row < rows) off = kfast ? row * ld : (rowmap ? (long)rowmap[row] : row);
+        float x[8];
+        if (vec && row < rows && kg * 8 + 8 <= K) {
+            const float4 lo = *reinterpret_cast<const float4 *>(src + off + kg * 8);
+            const float4 hi = *reinterpret_cast<const float4 *>(src + off + kg * 8 + 4);
+            x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w;
+            x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long k = kg * 8 + j;
-            float x = 0.f;
-            if (row < rows && k < K) x = kfast ? src[off + k] : src[k * ld + off];
-            b3_split(x, t1[j], t2[j], t3[j]);
+            for (int j = 0; j < 8; ++j) {
+                const long k = kg * 8 + j;
+                x[j] = 0.f;
+                if (row < rows && k < K) x[j] = kfast ? src[off + k] : src[k * ld + off];
+            }
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b3_split(x[j], t1[j], t2[j], t3[j]);
         i32x4 v1, v2, v3;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -100,7 +124,7 @@ int skm_b3_split(SkmCtx *ctx, const float *src, long rows, long K, long ld, int 
 {
     SKM_REQUIRE(ctx && src && dst && rows > 0 && K > 0, "b3_split(%s): bad argument", tag);
     const long Rp = b3_pad(rows, B3_TILE), KG = b3_pad(K, B3_BK) / 8;
-    long blocks = (Rp * KG + 255) / 256;
+    long blocks = (Rp * ((KG + 3) / 4 * 4) + 255) / 256;
     if (blocks > (long)ctx->cu_count * 32) blocks = (long)ctx->cu_count * 32;
     SkmProfScope ps(ctx, tag, st);
     hipLaunchKernelGGL(k_b3_split, dim3((unsigned)blocks), dim3(256), 0, st, src, rows, K, ld, kfast, rowmap,
