@@ -271,6 +271,14 @@ int skm_tv_estep(void *ctx, const float *naug_dev, const float *ftilde_dev, long
  * skm_tv_ftilde_planes_bytes(S, C, D) bytes) and handed to every iteration.  ft_planes_dev = NULL, SKM_TV_SPLIT=0 or
  * SKM_TV_PRECISE: exactly skm_tv_estep.  The C accumulation takes the planes only when batch is a multiple of 16. */
 size_t skm_tv_ftilde_planes_bytes(long S, int C, int D);
+/* extract_ivectors reads f~ once, for the aux product only: skm_tv_whiten_planes is skm_tv_whiten (same values, same
+ * naug) writing the rows image of the planes (skm_tv_ftilde_rows_bytes(S, C, D) bytes, the first part of what
+ * skm_tv_ftilde_planes builds) instead of the float32 matrix; skm_tv_estep_planes then takes ftilde_dev = NULL with
+ * these planes for extraction (A_aug_dev = NULL, not SKM_TV_PRECISE).  sidekit/factor_analyser.py:76-79, 88. */
+size_t skm_tv_ftilde_rows_bytes(long S, int C, int D);
+int skm_tv_whiten_planes(void *ctx, const void *stat0_dev, const void *stat1_dev, int in_f64, long S, int C, int D,
+                         const double *mu_dev, const double *sqrt_invcov_dev, void *rows_planes_dev, float *naug_dev,
+                         void *stream);
 int skm_tv_ftilde_planes(void *ctx, const float *ftilde_dev, long S, int C, int D, void *planes_dev, void *stream);
 int skm_tv_estep_planes(void *ctx, const float *naug_dev, const float *ftilde_dev, const void *ft_planes_dev, long S,
                         int C, int D, int R, const float *T32_dev, const float *G_dev, int batch, double *A_aug_dev,

@@ -59,6 +59,69 @@ __global__ __launch_bounds__(256) void k_tv_whiten(const TS *__restrict__ stat0,
     }
 }
 
+// The same whitening written straight into the rows image of the bf16 x 3 planes of f~ (skm_gemm_b3.hip:
+// planes[3][KG][Sp][8 bf16], k = supervector index): what extract_ivectors needs of f~ is the aux product only, which
+// the split GEMM takes from these planes; the float32 f~ is never stored.  Values are exactly those of k_tv_whiten
+// (same float64 arithmetic, same float32 roundings) and the split of a float32 value is exact.  Thread walk as in
+// k_b3_split for a k-fast source: four threads per 128 bytes of a session's statistics, rows four threads apart.
+typedef int tv_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned tv_bf16_rn(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+template <typename TS>
+__global__ __launch_bounds__(256) void k_tv_whiten_planes(const TS *__restrict__ stat0, const TS *__restrict__ stat1,
+                                                          long S, int C, int D, const double *__restrict__ mu,
+                                                          const double *__restrict__ sqrt_ic, tv_i32x4 *__restrict__ dst,
+                                                          long Sp, long KG, float *__restrict__ naug, int ldn)
+{
+    const long CD = (long)C * D, total = Sp * KG, KQ = (KG + 3) / 4, walk = Sp * KQ * 4;
+    for (long w = (long)blockIdx.x * blockDim.x + threadIdx.x; w < walk; w += (long)gridDim.x * blockDim.x) {
+        const long q = w / (Sp * 4), rem = w - q * (Sp * 4);
+        const long s = rem >> 2, kg = q * 4 + (rem & 3);
+        if (kg >= KG) continue;
+        unsigned t1[8], t2[8], t3[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long idx = kg * 8 + j;
+            float x = 0.f;
+            if (s < S && idx < CD) {
+                const double n = (double)stat0[s * C + idx / D];
+                const long i = s * CD + idx;
+                if (sizeof(TS) == 4) {
+                    const float a = (float)((double)stat1[i] - n * mu[idx]);
+                    x = (float)((double)a * sqrt_ic[idx]);
+                } else {
+                    x = (float)(((double)stat1[i] - n * mu[idx]) * sqrt_ic[idx]);
+                }
+            }
+            t1[j] = tv_bf16_rn(x);
+            const float r1 = x - __uint_as_float(t1[j] << 16);
+            t2[j] = tv_bf16_rn(r1);
+            const float r2 = r1 - __uint_as_float(t2[j] << 16);
+            t3[j] = tv_bf16_rn(r2);
+        }
+        tv_i32x4 v1, v2, v3;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            v1[h] = (int)(t1[2 * h] | (t1[2 * h + 1] << 16));
+            v2[h] = (int)(t2[2 * h] | (t2[2 * h + 1] << 16));
+            v3[h] = (int)(t3[2 * h] | (t3[2 * h + 1] << 16));
+        }
+        const long o = kg * Sp + s;
+        dst[o] = v1;
+        dst[total + o] = v2;
+        dst[2 * total + o] = v3;
+    }
+    const long totn = S * ldn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < totn; i += (long)gridDim.x * blockDim.x) {
+        const long s = i / ldn;
+        const int c = (int)(i - s * ldn);
+        naug[i] = (c < C) ? (float)stat0[s * C + c] : (c == C ? 1.0f : 0.0f);
+    }
+}
+
 // Column map of the flattened "upper part" view of an R x R matrix: row z keeps the columns from the start of its
 // 4-wide block (TV_BLK: 16-byte vectors stay aligned; 80 800 of 160 000 entries at R = 400, the exact triangle has
 // 80 200): for row z (block b = z / TV_BLK) the logical columns start(z) .. start(z) + R - TV_BLK b - 1 map to element
@@ -680,6 +743,34 @@ extern "C" int skm_tv_prepare(void *ctx_, const double *T, int C, int D, int R, 
 // Planes of f~ for skm_tv_estep_planes: [ rows image: sessions x (k = supervector) | columns image: supervector x (k = sessions) ]
 static size_t tv_ft_rows_bytes(long S, int C, int D) { return skm_align_up(skm_b3_plane_bytes(S, (long)C * D), 256); }
 
+extern "C" size_t skm_tv_ftilde_rows_bytes(long S, int C, int D)
+{
+    if (S <= 0 || C <= 0 || D <= 0) return 0;
+    return tv_ft_rows_bytes(S, C, D);
+}
+
+extern "C" int skm_tv_whiten_planes(void *ctx_, const void *stat0, const void *stat1, int in_f64, long S, int C, int D,
+                                    const double *mu, const double *sqrt_ic, void *rows_planes, float *naug, void *stream)
+{
+    SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
+    SKM_REQUIRE(ctx && stat0 && stat1 && mu && sqrt_ic && rows_planes && naug, "skm_tv_whiten_planes: NULL argument");
+    SKM_REQUIRE(S > 0 && C > 0 && D > 0, "skm_tv_whiten_planes: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const long Sp = skm_b3_rows_padded(S), KG = skm_b3_kgroups((long)C * D);
+    const int blocks = ctx->cu_count * 32;
+    SkmProfScope ps(ctx, "k_tv_whiten_planes", st);
+    if (in_f64)
+        hipLaunchKernelGGL(k_tv_whiten_planes<double>, dim3(blocks), dim3(256), 0, st, static_cast<const double *>(stat0),
+                           static_cast<const double *>(stat1), S, C, D, mu, sqrt_ic, static_cast<tv_i32x4 *>(rows_planes),
+                           Sp, KG, naug, tv_ldn(C));
+    else
+        hipLaunchKernelGGL(k_tv_whiten_planes<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float *>(stat0),
+                           static_cast<const float *>(stat1), S, C, D, mu, sqrt_ic, static_cast<tv_i32x4 *>(rows_planes),
+                           Sp, KG, naug, tv_ldn(C));
+    SKM_HIP(hipGetLastError());
+    return SKM_OK;
+}
+
 extern "C" size_t skm_tv_ftilde_planes_bytes(long S, int C, int D)
 {
     if (S <= 0 || C <= 0 || D <= 0) return 0;
@@ -708,7 +799,11 @@ static int tv_estep_impl(void *ctx_, const float *naug, const float *ftilde, lon
                          const void *ft_planes)
 {
     SkmCtx *ctx = static_cast<SkmCtx *>(ctx_);
-    SKM_REQUIRE(ctx && naug && ftilde && T32 && G && e_h && ws_, "skm_tv_estep: NULL argument");
+    SKM_REQUIRE(ctx && naug && T32 && G && e_h && ws_, "skm_tv_estep: NULL argument");
+    // extraction may come with the rows image of the planes alone (skm_tv_whiten_planes): no float32 f~ then
+    SKM_REQUIRE(ftilde || (ft_planes && !A_aug && chain != SKM_TV_PRECISE && tv_split()),
+                "skm_tv_estep: f~ may only be NULL for extraction from its planes (not training, not SKM_TV_PRECISE, "
+                "not with SKM_TV_SPLIT=0)");
     SKM_REQUIRE(S > 0 && C > 0 && D > 0 && R > 0 && batch > 0, "skm_tv_estep: bad shape");
     SKM_REQUIRE((A_aug == nullptr) == (Cacc == nullptr), "skm_tv_estep: A_aug and Cacc go together");
     const bool precise = chain == SKM_TV_PRECISE;

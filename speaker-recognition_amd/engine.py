@@ -77,6 +77,9 @@ SIGNATURES = {
                               _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                               _c_void_p, _c_size_t, _c_void_p]),
     "skm_tv_ftilde_planes_bytes": (_c_size_t, [_c_long, _c_int, _c_int]),
+    "skm_tv_ftilde_rows_bytes": (_c_size_t, [_c_long, _c_int, _c_int]),
+    "skm_tv_whiten_planes": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_int, _c_int, _c_void_p,
+                                      _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "skm_tv_ftilde_planes": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p]),
     "skm_tv_estep_planes": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int, _c_void_p,
                                      _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
@@ -800,6 +803,28 @@ class HipEngine(object):
                                            _c_void_p(ft.data_ptr()), _c_void_p(naug.data_ptr()), self._stream()))
         return ft, naug
 
+    def tv_whiten_planes(self, stat0, stat1, mu_sv, invcov_sv):
+        """tv_whiten for extract_ivectors: (rows image of the bf16 x 3 planes of ftilde, naug) -- the float32 ftilde
+        is never stored; tv_estep(naug, None, ..., ft_planes=planes) takes the aux product from the planes.  None
+        instead of the planes when the split products are switched off (SKM_TV_SPLIT=0 / SKM_TV_FT_PLANES=0)."""
+        import os
+        torch = self.torch
+        if os.environ.get("SKM_TV_FT_PLANES", "1") == "0" or os.environ.get("SKM_TV_SPLIT", "1") == "0":
+            return None, None
+        S, C = stat0.shape
+        D = stat1.shape[1] // C
+        assert stat0.dtype == stat1.dtype and stat0.dtype in (torch.float32, torch.float64)
+        assert stat0.is_contiguous() and stat1.is_contiguous()
+        mu = torch.as_tensor(_as_f64(mu_sv)).to(self.device)
+        sq = torch.as_tensor(np.sqrt(_as_f64(invcov_sv))).to(self.device)
+        planes = torch.empty(int(self.lib.skm_tv_ftilde_rows_bytes(S, C, D)), dtype=torch.uint8, device=self.device)
+        naug = torch.empty((S, self.lib.skm_tv_naug_stride(C)), dtype=torch.float32, device=self.device)
+        self._check(self.lib.skm_tv_whiten_planes(self.ctx, _c_void_p(stat0.data_ptr()), _c_void_p(stat1.data_ptr()),
+                                                  1 if stat0.dtype == torch.float64 else 0, S, C, D,
+                                                  _c_void_p(mu.data_ptr()), _c_void_p(sq.data_ptr()),
+                                                  _c_void_p(planes.data_ptr()), _c_void_p(naug.data_ptr()), self._stream()))
+        return planes, naug
+
     def tv_prepare(self, T, C, D):
         """(T32, G) for the loading matrix T (CD x R float64 device tensor)."""
         torch = self.torch
@@ -850,8 +875,13 @@ class HipEngine(object):
         ws = self.workspace(need)
         null = _c_void_p(None)
         if ft_planes is not None:
-            assert ft_planes.numel() == self.lib.skm_tv_ftilde_planes_bytes(S, C, D), "ft_planes of another shape"
-        self._check(self.lib.skm_tv_estep_planes(self.ctx, _c_void_p(naug.data_ptr()), _c_void_p(ft.data_ptr()),
+            full = self.lib.skm_tv_ftilde_planes_bytes(S, C, D)
+            rows = self.lib.skm_tv_ftilde_rows_bytes(S, C, D)
+            assert ft_planes.numel() == full or (ft_planes.numel() == rows and A_aug is None), "ft_planes of another shape"
+        assert ft is not None or (ft_planes is not None and A_aug is None and T64 is None), \
+            "ft may only be None for extraction from its planes"
+        self._check(self.lib.skm_tv_estep_planes(self.ctx, _c_void_p(naug.data_ptr()),
+                                          _c_void_p(ft.data_ptr()) if ft is not None else null,
                                           _c_void_p(ft_planes.data_ptr()) if ft_planes is not None else null, S, C, D, R,
                                           _c_void_p(T32.data_ptr()), _c_void_p(G.data_ptr()), batch,
                                           _c_void_p(A_aug.data_ptr()) if A_aug is not None else null,

@@ -51,6 +51,14 @@ def _upload_f32(eng, a):
 EXTRACT_BATCH = 16384
 
 
+class _FtPlanes(object):
+    """f~ of a set of sessions as the rows image of its bf16 x 3 planes (engine.tv_whiten_planes): what
+    extract_ivectors keeps instead of the float32 matrix."""
+
+    def __init__(self, planes):
+        self.planes = planes
+
+
 class FactorAnalyser(object):
     def __init__(self, input_file_name=None, mean=None, F=None, G=None, H=None, Sigma=None, engine=None):
         self.mean = None
@@ -129,10 +137,20 @@ class FactorAnalyser(object):
         return ".h5" if _has_h5py() else ".npz"
 
     # ------------------------------------------------------------------ device helpers
-    def _resident_stats(self, sources, ubm, prefix=''):
-        """Whitened statistics of THIS rank's sessions in HBM: (ftilde, naug, total sessions, local slice)."""
+    def _resident_stats(self, sources, ubm, prefix='', rows_planes=False):
+        """Whitened statistics of THIS rank's sessions in HBM: (ftilde, naug, total sessions, local slice).
+        rows_planes (extraction from ONE source): ftilde comes back as _FtPlanes -- the rows image of its bf16 x 3
+        planes, written by the whitening itself (engine.tv_whiten_planes) -- when the engine offers that."""
         eng = self.engine
         torch = eng.torch
+        rows_planes = rows_planes and len(sources) == 1 and hasattr(eng, "tv_whiten_planes")
+
+        def whiten(d0, d1):
+            if rows_planes:
+                planes, naug = eng.tv_whiten_planes(d0, d1, ubm.get_mean_super_vector(), ubm.get_invcov_super_vector())
+                if planes is not None:
+                    return _FtPlanes(planes), naug
+            return eng.tv_whiten(d0, d1, ubm.get_mean_super_vector(), ubm.get_invcov_super_vector())
         fts, naugs, total, local = [], [], 0, []
         for src in sources:
             res = src.resident_rows() if isinstance(src, StatServer) else None
@@ -145,8 +163,7 @@ class FactorAnalyser(object):
                     local.append((total + a, total + b))
                     total += n
                     if b > a:
-                        ft, naug = eng.tv_whiten(res[1], res[2], ubm.get_mean_super_vector(),
-                                                 ubm.get_invcov_super_vector())
+                        ft, naug = whiten(res[1], res[2])
                         fts.append(ft)
                         naugs.append(naug)
                     continue
@@ -158,7 +175,8 @@ class FactorAnalyser(object):
             if b > a:
                 d0 = _upload_f32(eng, s0[a:b])
                 d1 = _upload_f32(eng, s1[a:b])
-                ft, naug = eng.tv_whiten(d0, d1, ubm.get_mean_super_vector(), ubm.get_invcov_super_vector())
+                ft, naug = whiten(d0, d1)
+                del d0, d1
                 fts.append(ft)
                 naugs.append(naug)
         if not fts:
@@ -417,7 +435,9 @@ class FactorAnalyser(object):
                     self.write(output_file_name + self._ext())
 
     # ------------------------------------------------------------------ extraction
-    def _extract(self, ft, naug, ubm, batch, uncertainty):
+    def _extract(self, ft, naug, ubm, batch, uncertainty, again=None):
+        """again(): the plain float32 f~ of the same sessions, for the one case the planes cannot serve -- the
+        all-float64 route that long sessions on trained loadings switch to (_estep_chain)."""
         eng = self.engine
         torch = eng.torch
         C, D = ubm.distrib_nb(), ubm.dim()
@@ -425,7 +445,14 @@ class FactorAnalyser(object):
         T32, G = eng.tv_prepare(T_dev, C, D)
         # without `uncertainty` the device solves L x = aux from the Cholesky factor and never forms U^-1
         chain, T64 = self._estep_chain(T_dev, naug, C, D)
-        e_h, sig = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=bool(uncertainty), chain=chain, T64=T64)
+        more = {}
+        if isinstance(ft, _FtPlanes):
+            if chain == "precise":
+                ft = again()
+            else:
+                ft, more = None, {"ft_planes": ft.planes}
+        e_h, sig = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, uncertainty=bool(uncertainty), chain=chain, T64=T64,
+                                **more)
         return e_h, sig
 
     @fanout
@@ -442,12 +469,16 @@ class FactorAnalyser(object):
         else:
             modelset, segset, start, stop, _, _ = _load_stat_arrays(stat_server_filename, prefix)
         nb_sessions = modelset.shape[0]
-        ft, naug, total, local = self._resident_stats([stat_server_filename], ubm, prefix)
+        # the whitening writes f~ as the planes the aux product reads (no float32 f~) unless the all-float64 route is
+        # asked for outright; should the bound on cond(L_s) pick that route for this call, f~ is whitened again
+        ft, naug, total, local = self._resident_stats([stat_server_filename], ubm, prefix,
+                                                      rows_planes=self.chain_precision != "precise")
         a, b = local[0]
         torch = eng.torch
         width = tv_rank * (2 if uncertainty else 1)
         if ft is not None:
-            e_h, sig = self._extract(ft, naug, ubm, EXTRACT_BATCH, uncertainty)
+            e_h, sig = self._extract(ft, naug, ubm, EXTRACT_BATCH, uncertainty,
+                                     again=lambda: self._resident_stats([stat_server_filename], ubm, prefix)[0])
             mine = torch.cat([e_h, sig], dim=1) if sig is not None else e_h
         else:
             mine = torch.zeros((0, width), dtype=torch.float64, device=getattr(eng, "device", "cpu"))

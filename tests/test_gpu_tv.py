@@ -202,6 +202,19 @@ def test_estep_with_ftilde_planes(eng):
     # extraction (no accumulators) through the planes route
     e_s, _ = eng.tv_estep(naug, ft, T32, G, C, D, batch=batch, ft_planes=planes)
     assert rel(eng.to_host(e_s)[:16], iv) < 2e-5
+    # extract_ivectors' whitening writes the rows image itself and keeps no float32 f~: the same bytes, the same
+    # naug, the same i-vectors from ft = None
+    rows, naug2 = eng.tv_whiten_planes(dev(eng, s0), dev(eng, s1), gmm.mu.flatten(), gmm.invcov.flatten())
+    assert torch.equal(rows, planes[:rows.numel()]) and torch.equal(naug2, naug)
+    e_r, _ = eng.tv_estep(naug2, None, T32, G, C, D, batch=batch, ft_planes=rows)
+    assert torch.equal(e_r, e_s)
+    rows64, _ = eng.tv_whiten_planes(dev(eng, s0.astype(np.float64)), dev(eng, s1.astype(np.float64)), gmm.mu.flatten(),
+                                     gmm.invcov.flatten())
+    ft64, _ = eng.tv_whiten(dev(eng, s0.astype(np.float64)), dev(eng, s1.astype(np.float64)), gmm.mu.flatten(),
+                            gmm.invcov.flatten())
+    assert torch.equal(rows64, eng.tv_ftilde_planes(ft64, C, D)[:rows64.numel()])
+    with pytest.raises(Exception):
+        eng.tv_estep(naug2, None, T32, G, C, D, batch=batch)             # no f~ at all
 
 
 def test_total_variability_dropin_vs_reference_golden(sk, tmp_path):
