@@ -758,8 +758,13 @@ def main():
             stat1[a0:b0] = (n_rep * mu_sv + torch.sqrt(n_rep) * sd_sv *
                             torch.randn(b0 - a0, Ct * D, generator=gen, device=dev, dtype=torch.float64)).to(torch.float32)
             del n_rep, post
-        ft, naug = eng.tv_whiten(stat0, stat1, ubm_t.get_mean_super_vector(), ubm_t.get_invcov_super_vector())
-        del stat1
+        mu_t, ic_t = ubm_t.get_mean_super_vector(), ubm_t.get_invcov_super_vector()
+        eng.tv_whiten(stat0[:64], stat1[:64], mu_t, ic_t)                       # first-call costs out of the timings
+        dt_wh, (ft, naug) = timed(lambda: eng.tv_whiten(stat0, stat1, mu_t, ic_t), 1)
+        # extract_ivectors' whitening: f~ straight into the rows image of its bf16 x 3 planes (no float32 f~ kept)
+        eng.tv_whiten_planes(stat0[:64], stat1[:64], mu_t, ic_t)
+        dt_whp, (ft_rows, _naug2) = timed(lambda: eng.tv_whiten_planes(stat0, stat1, mu_t, ic_t), 1)
+        del stat1, _naug2
         torch.cuda.empty_cache()
         fa = sk.FactorAnalyser()
         tv_state = {"T": torch.as_tensor(0.1 * np.random.RandomState(7).randn(Ct * D, R), device=dev)}
@@ -784,9 +789,11 @@ def main():
         del ft_planes                        # extraction is a single pass over f~: no planes (nothing to amortise)
         torch.cuda.empty_cache()
         T32, G = eng.tv_prepare(tv_state["T"], Ct, D)
-        dt_iv, _ = timed(lambda: eng.tv_estep(naug, ft, T32, G, Ct, D, batch=args.tv_extract_batch, uncertainty=False), 1)
+        ex = {"ft_planes": ft_rows} if ft_rows is not None else {}
+        ft_ex = None if ft_rows is not None else ft             # as FactorAnalyser.extract_ivectors runs it
+        dt_iv, _ = timed(lambda: eng.tv_estep(naug, ft_ex, T32, G, Ct, D, batch=args.tv_extract_batch, uncertainty=False, **ex), 1)
         prof_iv = eng.profile_read()
-        dt_ivu, _ = timed(lambda: eng.tv_estep(naug, ft, T32, G, Ct, D, batch=args.tv_extract_batch, uncertainty=True), 1)
+        dt_ivu, _ = timed(lambda: eng.tv_estep(naug, ft_ex, T32, G, Ct, D, batch=args.tv_extract_batch, uncertainty=True, **ex), 1)
         eng.profile_read()
         eng.profile(False)
         flop_train, flop_iv = 9.18e8, 4.5e8          # algorithmic flop per session
@@ -825,6 +832,11 @@ def main():
                                                  / PEAK_F32_MFMA_TFLOPS) if prof_tv.get("k_gemm_lbuild", (0, 0))[1] else None,
                 "aacc_frac_of_f32_mfma_peak": (2.0 * Ct * (R * (R + 1) // 2) * St / (prof_tv["k_gemm_aacc"][1] * 1e-3) / 1e12
                                                / PEAK_F32_MFMA_TFLOPS) if prof_tv.get("k_gemm_aacc", (0, 0))[1] else None},
+            "whitening": {"seconds_float32_ftilde": dt_wh, "seconds_rows_planes": dt_whp,
+                          "extraction_from_planes": ft_rows is not None,
+                          "note": "the whitening of the statistics (factor_analyser.py:76-79) is outside train_s_per_iteration "
+                                  "and outside the extraction times, as in rounds 1-2; extract_ivectors uses the variant that "
+                                  "writes f~ as bf16 x 3 planes (its aux product then runs on the bf16 matrix cores)"},
             "ftilde_planes": {"used": planes_used, "seconds_once_per_training_run": t_pl,
                               "note": "f~ split into three bf16 terms in both orientations (12 B per element) once per "
                                       "training run; every iteration's aux = f~ T and C += e_h' f~ then run on the bf16 "
@@ -833,7 +845,7 @@ def main():
             "extract_kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof_iv.items())},
             "note": "M-step cost (R x R inverses of the rank's C/N components) is independent of the session count; it is "
                     "included in train_s_per_iteration"}
-        del ft, naug, T32, G, stat0
+        del ft, naug, T32, G, stat0, ft_rows, ex
         torch.cuda.empty_cache()
         if rank == 0 and world == 1:
             # API level on a bounded sample: FactorAnalyser.total_variability (one iteration) and extract_ivectors on

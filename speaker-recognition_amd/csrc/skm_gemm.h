@@ -100,8 +100,11 @@ int skm_b3_split(SkmCtx *ctx, const float *src, long rows, long K, long ld, int 
 // C[m * ldc + (colmap ? colmap[n] : n)] (+)= sum_k A(m, k) B(n, k) from split planes; C float or double.
 // plane_a / plane_b: distance between the three planes of A / B in 16-byte units when the product runs over a k range
 // of larger planes (Ap / Bp then point at the first k-group of the range in plane 0); 0 = planes of exactly K.
+// nz > 1: nz independent products in one launch (split-K slabs): product z reads Ap + 16 zA z, Bp + 16 zB z bytes and
+// writes C + zC z elements.
 int skm_b3_gemm(SkmCtx *ctx, const void *Ap, long M, const void *Bp, long N, long K, void *C, int c_f64, long ldc,
-                const int *colmap, int accumulate, hipStream_t st, const char *tag, long plane_a = 0, long plane_b = 0);
+                const int *colmap, int accumulate, hipStream_t st, const char *tag, long plane_a = 0, long plane_b = 0,
+                int nz = 1, long zA = 0, long zB = 0, long zC = 0);
 // padded row count / k-groups of a planes image (layout arithmetic for callers that address k ranges)
 long skm_b3_rows_padded(long rows);
 long skm_b3_kgroups(long K);

@@ -145,6 +145,8 @@ struct B3Args {
     int accumulate;
     int tiles_m, tiles_n;
     int swap;                 // XCD-aware tile order: 0 = an XCD walks the M tiles of one N tile, 1 = the N tiles of one M tile
+    long zA, zB, zC;          // blockIdx.y = z: independent products of one launch (split-K slabs): A, B advance by
+                              // zA, zB 16-byte units (k ranges of the same planes), C by zC elements
 };
 
 template <typename TO>
@@ -164,6 +166,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_b3(B3Args g)
     const int tn = g.swap ? fast_i : slow_i, tm = g.swap ? slow_i : fast_i;
     if (tn >= g.tiles_n || tm >= g.tiles_m) return;
     const long m0 = (long)tm * B3_TILE, n0 = (long)tn * B3_TILE;
+    const long z = blockIdx.y;
+    g.A += z * g.zA;
+    g.B += z * g.zB;
 
     // Staging: the stages go from L2 straight into LDS (buffer_load ... lds, 16 bytes per lane: one instruction of a
     // wave fills 64 consecutive rows of one k-group of one plane = 1 KB of the stage), two stages ahead of the one
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_b3(B3Args g)
     // columns beyond the matrix are clamped to its last ones for the load and masked for the store): with the load
     // inside the bounds test hipcc waited for every single one (128 round trips to HBM per wave, a quarter of the A
     // accumulation's time).
-    TO *C = static_cast<TO *>(g.C);
+    TO *C = static_cast<TO *>(g.C) + z * g.zC;
     long colv[2];
     bool okn[2];
 #pragma unroll
@@ -314,7 +319,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_b3(B3Args g)
 }
 
 int skm_b3_gemm(SkmCtx *ctx, const void *Ap, long M, const void *Bp, long N, long K, void *C, int c_f64, long ldc,
-                const int *colmap, int accumulate, hipStream_t st, const char *tag, long plane_a, long plane_b)
+                const int *colmap, int accumulate, hipStream_t st, const char *tag, long plane_a, long plane_b, int nz,
+                long zA, long zB, long zC)
 {
     SKM_REQUIRE(ctx && Ap && Bp && C && M > 0 && N > 0 && K > 0, "b3_gemm(%s): bad argument", tag);
     B3Args g;
@@ -333,6 +339,10 @@ int skm_b3_gemm(SkmCtx *ctx, const void *Ap, long M, const void *Bp, long N, lon
     g.accumulate = accumulate;
     g.tiles_m = (int)(g.Mp / B3_TILE);
     g.tiles_n = (int)(g.Np / B3_TILE);
+    SKM_REQUIRE(nz >= 1 && nz <= 65535, "b3_gemm(%s): bad slab count %d", tag, nz);
+    g.zA = zA;
+    g.zB = zB;
+    g.zC = zC;
     g.swap = g.tiles_n < g.tiles_m;
     const long grid = g.swap ? (long)((g.tiles_m + 7) / 8 * 8) * g.tiles_n : (long)((g.tiles_n + 7) / 8 * 8) * g.tiles_m;
     SKM_REQUIRE(grid < 0x7FFFFFFFL, "b3_gemm(%s): grid too large", tag);
@@ -341,9 +351,9 @@ int skm_b3_gemm(SkmCtx *ctx, const void *Ap, long M, const void *Bp, long N, lon
                 "b3_gemm(%s): a plane of an operand exceeds 4 GB (M=%ld N=%ld K=%ld)", tag, M, N, K);
     SkmProfScope ps(ctx, tag, st);
     if (c_f64)
-        hipLaunchKernelGGL(k_gemm_b3<double>, dim3((unsigned)grid), dim3(512), 0, st, g);
+        hipLaunchKernelGGL(k_gemm_b3<double>, dim3((unsigned)grid, (unsigned)nz), dim3(512), 0, st, g);
     else
-        hipLaunchKernelGGL(k_gemm_b3<float>, dim3((unsigned)grid), dim3(512), 0, st, g);
+        hipLaunchKernelGGL(k_gemm_b3<float>, dim3((unsigned)grid, (unsigned)nz), dim3(512), 0, st, g);
     SKM_HIP(hipGetLastError());
     return SKM_OK;
 }

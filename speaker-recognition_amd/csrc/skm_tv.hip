@@ -82,18 +82,54 @@ __global__ __launch_bounds__(256) void k_tv_whiten_planes(const TS *__restrict__
         const long s = rem >> 2, kg = q * 4 + (rem & 3);
         if (kg >= KG) continue;
         unsigned t1[8], t2[8], t3[8];
+        // one division per thread: the component of the first of the 8 columns, then a running remainder
+        const long k0 = kg * 8;
+        int c = (int)(k0 / D), r = (int)(k0 - (long)c * D);
+        const bool whole = s < S && k0 + 8 <= CD;
+        TS raw[8];
+        double m8[8], q8[8];
+        if (whole) {
+            const TS *p1 = stat1 + s * CD + k0;
+            if (((uintptr_t)p1 & 15) == 0) {
+                typedef TS vec_t __attribute__((ext_vector_type(16 / sizeof(TS))));
+                constexpr int VW = 16 / sizeof(TS);
+#pragma unroll
+                for (int v = 0; v < 8 / VW; ++v) {
+                    const vec_t t = *reinterpret_cast<const vec_t *>(p1 + v * VW);
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) raw[v * VW + e] = t[e];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) raw[j] = p1[j];
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {               // k0 is a multiple of 8: 64-byte aligned doubles
+                const double2 a = *reinterpret_cast<const double2 *>(mu + k0 + 2 * v);
+                const double2 b = *reinterpret_cast<const double2 *>(sqrt_ic + k0 + 2 * v);
+                m8[2 * v] = a.x; m8[2 * v + 1] = a.y;
+                q8[2 * v] = b.x; q8[2 * v + 1] = b.y;
+            }
+        }
+        double n = (s < S && k0 < CD) ? (double)stat0[s * C + c] : 0.0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const long idx = kg * 8 + j;
+            const long idx = k0 + j;
+            if (r == D) {
+                r = 0;
+                ++c;
+                n = (s < S && idx < CD) ? (double)stat0[s * C + c] : 0.0;
+            }
+            ++r;
             float x = 0.f;
             if (s < S && idx < CD) {
-                const double n = (double)stat0[s * C + idx / D];
-                const long i = s * CD + idx;
+                const double v1 = whole ? (double)raw[j] : (double)stat1[s * CD + idx];
+                const double mj = whole ? m8[j] : mu[idx], qj = whole ? q8[j] : sqrt_ic[idx];
                 if (sizeof(TS) == 4) {
-                    const float a = (float)((double)stat1[i] - n * mu[idx]);
-                    x = (float)((double)a * sqrt_ic[idx]);
+                    const float a = (float)(v1 - n * mj);
+                    x = (float)((double)a * qj);
                 } else {
-                    x = (float)(((double)stat1[i] - n * mu[idx]) * sqrt_ic[idx]);
+                    x = (float)((v1 - n * mj) * qj);
                 }
             }
             t1[j] = tv_bf16_rn(x);
@@ -865,11 +901,24 @@ static int tv_estep_impl(void *ctx_, const float *naug, const float *ftilde, lon
         if ((rc = skm_b3_split(ctx, T32, R, CD, R, 0, nullptr, Tp, st, "k_b3_split"))) return rc;
         const long Sp = skm_b3_rows_padded(S), Rp = skm_b3_rows_padded(R), KGt = skm_b3_kgroups(CD);
         const char *fa = static_cast<const char *>(ft_planes);
-        for (long k0 = 0; k0 < CD; k0 += TV_AUX_CHUNK_B3) {
-            const long kn = (CD - k0) < TV_AUX_CHUNK_B3 ? (CD - k0) : TV_AUX_CHUNK_B3;
+        // few sessions = few 256 x 256 output tiles (4000 sessions: 32): K is then cut into nz slabs that run side by
+        // side in one launch (float64 slabs, summed afterwards), like the split-K of the float32 route
+        int nz = 1;
+        const long tiles = (Sp / 256) * (Rp / 256);
+        while (nz * 2 <= w.ksplit && tiles * nz < 2L * ctx->cu_count && (CD / (nz * 2)) % 16 == 0 && CD % (nz * 2) == 0) nz *= 2;
+        const long Kz = CD / nz;
+        double *out = nz > 1 ? reinterpret_cast<double *>(ws + w.off_auxs) : aux;
+        for (long k0 = 0; k0 < Kz; k0 += TV_AUX_CHUNK_B3) {
+            const long kn = (Kz - k0) < TV_AUX_CHUNK_B3 ? (Kz - k0) : TV_AUX_CHUNK_B3;
             if ((rc = skm_b3_gemm(ctx, fa + (k0 / 8) * Sp * 16, S, static_cast<const char *>(Tp) + (k0 / 8) * Rp * 16, R, kn,
-                                  aux, 1, R, nullptr, k0 ? 1 : 0, st, "k_gemm_aux", KGt * Sp, KGt * Rp)))
+                                  out, 1, R, nullptr, k0 ? 1 : 0, st, "k_gemm_aux", KGt * Sp, KGt * Rp, nz, (Kz / 8) * Sp,
+                                  (Kz / 8) * Rp, S * R)))
                 return rc;
+        }
+        if (nz > 1) {
+            SkmProfScope ps(ctx, "k_sum_slabs", st);
+            hipLaunchKernelGGL(k_sum_slabs, dim3(ctx->cu_count * 2), dim3(256), 0, st, aux, out, S * R, nz);
+            SKM_HIP(hipGetLastError());
         }
     } else if (w.ksplit > 1) {
         double *slabs = reinterpret_cast<double *>(ws + w.off_auxs);
