@@ -309,13 +309,15 @@ __global__ __launch_bounds__(256) void k_tv_finish_tri(const T *__restrict__ X, 
     // y = X' aux: y[j] = sum_{i<=j} X[i][j] aux[i]   (column sweep, coalesced along j)
     for (int j = t; j < R; j += 256) {
         double s = 0.0;
-        for (int i = 0; i <= j; ++i) s += (double)Xi[(long)i * R + j] * ax[i];
+#pragma unroll 8
+        for (int i = 0; i <= j; ++i) s += (double)Xi[(long)i * R + j] * ax[i];      // 8 loads in flight
         y[j] = s;
     }
     __syncthreads();
     // e_h[i] = sum_{j>=i} X[i][j] y[j], diag[i] = sum_{j>=i} X[i][j]^2   (row reduce, one wave per row)
     for (int i = wave; i < R; i += 4) {
         double s = 0.0, d = 0.0;
+#pragma unroll 7
         for (int j = i + lane; j < R; j += 64) {
             const double x = (double)Xi[(long)i * R + j];
             s += x * y[j];
@@ -357,8 +359,10 @@ __global__ __launch_bounds__(256) void k_tv_solve(const T *__restrict__ Ub, int 
         const int r0 = k * CH_BLK, bs = (R - r0 < CH_BLK) ? (R - r0) : CH_BLK;
         // column sums over the rows above the block: lane = column, wave = row phase (coalesced along the row)
         double s = 0.0;
-        if (lane < bs)
-            for (int i = wave; i < r0; i += 4) s += (double)U[(long)i * R + r0 + lane] * y[i];
+        if (lane < bs) {
+#pragma unroll 8
+            for (int i = wave; i < r0; i += 4) s += (double)U[(long)i * R + r0 + lane] * y[i];      // 8 loads in flight
+        }
         part[wave * CH_BLK + lane] = s;
         __syncthreads();
         if (t < bs) tv[t] = y[r0 + t] - ((part[t] + part[CH_BLK + t]) + (part[2 * CH_BLK + t] + part[3 * CH_BLK + t]));
@@ -377,6 +381,7 @@ __global__ __launch_bounds__(256) void k_tv_solve(const T *__restrict__ Ub, int 
         const int r0 = k * CH_BLK, bs = (R - r0 < CH_BLK) ? (R - r0) : CH_BLK, c0 = r0 + bs;
         for (int r = wave; r < bs; r += 4) {
             double s = 0.0;
+#pragma unroll 6
             for (int j = c0 + lane; j < R; j += 64) s += (double)U[(long)(r0 + r) * R + j] * y[j];
 #pragma unroll
             for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
