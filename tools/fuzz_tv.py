@@ -75,6 +75,13 @@ for case in range(CASES):
         e_h, sig = eng.tv_estep(naug, ft, T32, Gd, C, D, batch=batch, A_aug=A_aug, Cacc=Cacc, uncertainty=True)
         e_s, _ = eng.tv_estep(naug, ft, T32, Gd, C, D, batch=batch, uncertainty=False)
         A_keep = A_aug.clone()
+        # the planes routes: training with f~ split once per run, extraction from the planes the whitening writes
+        planes = eng.tv_ftilde_planes(ft, C, D)
+        A_p = torch.zeros_like(A_aug)
+        C_p = torch.zeros_like(Cacc)
+        e_p, sig_p = eng.tv_estep(naug, ft, T32, Gd, C, D, batch=batch, A_aug=A_p, Cacc=C_p, uncertainty=True, ft_planes=planes)
+        rows, naug_r = eng.tv_whiten_planes(s0d, s1d, mu, invcov)
+        e_r, _ = eng.tv_estep(naug_r, None, T32, Gd, C, D, batch=batch, uncertainty=False, ft_planes=rows)
         Fn = eng.tv_mstep(A_aug, Cacc, C, D, R)
         torch.cuda.synchronize()
     except Exception as ex:
@@ -87,7 +94,9 @@ for case in range(CASES):
     cosv = torch.nn.functional.cosine_similarity(e_h, e, dim=1).min().item()
     errs = {"ft": rel(ft.double(), f), "A": rel(upper(A_keep[:C].reshape(C, R, R)), upper(A_ref[:C])),
             "R": rel(upper(A_keep[C].reshape(R, R)), upper(A_ref[C])), "C": rel(Cacc, C_ref),
-            "e": rel(e_h, e), "sig": rel(sig, sig_ref), "e_solve": rel(e_s, e), "F": rel(Fn, Fr), "1-cos": 1.0 - cosv}
+            "e": rel(e_h, e), "sig": rel(sig, sig_ref), "e_solve": rel(e_s, e), "F": rel(Fn, Fr), "1-cos": 1.0 - cosv,
+            "A_pl": rel(upper(A_p[:C].reshape(C, R, R)), upper(A_ref[:C])), "C_pl": rel(C_p, C_ref), "e_pl": rel(e_p, e),
+            "e_rows": rel(e_r, e)}
     cond = torch.linalg.cond(L).max().item()
     # fewer sessions than factors: A_c is nearly singular and the M-step solve magnifies the 1e-6 of its inputs; shown,
     # not judged
