@@ -505,6 +505,7 @@ struct TvWs {
     size_t off_tp, off_ep;                      // planes of the loading matrix (aux product) and of a batch's e_h' (C accumulation)
     size_t off_g64, off_f64, off_n64;           // SKM_TV_PRECISE: float64 Gram matrices, f~ rows and N of a chunk
     int ksplit;
+    int nzb3;       // split-K slabs of the aux product on the split GEMM (tv_nz_b3)
 };
 
 // The L build and the A accumulation run on the bf16 matrix cores from operands split into three bf16 terms
@@ -530,6 +531,17 @@ static int tv_cacc_kind()
         return (e && !strcmp(e, "big")) ? SKM_GEMM_F32_F64OUT : SKM_GEMM_F32S_F64OUT;
     }();
     return kind;
+}
+
+// The same question for the aux product on the split GEMM (256 x 256 tiles, f~ from its planes): K is cut into slabs
+// that run side by side in one launch until the launch makes at least 8 rounds over the CUs -- 4000 sessions are 32
+// tiles, and the 392 tiles of 50 000 sessions are one full round and one half-empty one (28.2 -> 22 ms with 8 slabs).
+static int tv_nz_b3(int cu, long S, int R, long CD)
+{
+    const long tiles = ((S + 255) / 256) * ((R + 255) / 256);
+    int nz = 1;
+    while (nz < 16 && tiles * nz < 8L * cu && CD % (nz * 2) == 0 && (CD / (nz * 2)) % 16 == 0) nz *= 2;
+    return nz;
 }
 
 static int tv_ksplit(int cu, long S, int R, int C)
@@ -563,8 +575,12 @@ static TvWs tv_ws(int R, long S, int batch, int cu = 256, int C = 0, int D = 0, 
     w.off_cs = off;
     off += skm_align_up((size_t)TV_CS_SPLIT * tv_tri_cols(R) * sizeof(double), 256);
     w.ksplit = (S > 0 && C > 0) ? tv_ksplit(cu, S, R, C) : 1;
+    w.nzb3 = (S > 0 && C > 0 && tv_split()) ? tv_nz_b3(cu, S, R, (long)C * D) : 1;
     w.off_auxs = off;
-    if (w.ksplit > 1) off += skm_align_up((size_t)w.ksplit * S * R * sizeof(double), 256);
+    {
+        const int slabs = w.ksplit > w.nzb3 ? w.ksplit : w.nzb3;
+        if (slabs > 1) off += skm_align_up((size_t)slabs * S * R * sizeof(double), 256);
+    }
     // M-step product Y[batch][D][R]: fits the L^-1 region when D <= R, else a region of its own
     w.off_y = w.off_linv;
     if (D > R) {
@@ -908,9 +924,7 @@ static int tv_estep_impl(void *ctx_, const float *naug, const float *ftilde, lon
         const char *fa = static_cast<const char *>(ft_planes);
         // few sessions = few 256 x 256 output tiles (4000 sessions: 32): K is then cut into nz slabs that run side by
         // side in one launch (float64 slabs, summed afterwards), like the split-K of the float32 route
-        int nz = 1;
-        const long tiles = (Sp / 256) * (Rp / 256);
-        while (nz * 2 <= w.ksplit && tiles * nz < 2L * ctx->cu_count && (CD / (nz * 2)) % 16 == 0 && CD % (nz * 2) == 0) nz *= 2;
+        const int nz = w.nzb3;
         const long Kz = CD / nz;
         double *out = nz > 1 ? reinterpret_cast<double *>(ws + w.off_auxs) : aux;
         for (long k0 = 0; k0 < Kz; k0 += TV_AUX_CHUNK_B3) {
