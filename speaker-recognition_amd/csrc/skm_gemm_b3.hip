@@ -18,10 +18,13 @@
 // Kernel: workgroup = 8 waves = 256 x 256 tile (wave: 128 x 64 = 4 x 2 MFMA blocks, 128 accumulator registers), BK = 16
 // (one MFMA k-step) per stage, a ring of three LDS stages of 48 KB filled by LDS-direct loads two stages ahead of the
 // one being multiplied (round 3: the first version staged through registers ONE stage ahead and waited for its loads
-// at the end of every stage), one barrier per stage; one workgroup per CU, two waves per SIMD.  Per stage and wave:
-// 6 buffer_load ... lds, 18 ds_read_b128, 48 MFMAs.  The tile is this large because the operands cost 6 bytes per
-// element and the loads come from L2: the first version (128 x 128 tiles) pulled 8 TB/s out of the L2s and stopped
-// there, at 0.43 of the bf16 MFMA rate.
+// at the end of every stage); one workgroup per CU, two waves per SIMD, and the two waves of a SIMD run one barrier
+// apart -- one reads its fragments while the other multiplies (two barriers per stage, see the loop).  Per stage and
+// wave: 6 buffer_load ... lds, 18 ds_read_b128, 48 MFMAs.  The tile is this large because the operands cost 6 bytes
+// per element and the loads come from L2: the first version (128 x 128 tiles) pulled 8 TB/s out of the L2s and stopped
+// there, at 0.43 of the bf16 MFMA rate.  Where it stands: the matrix pipe busy 0.83 of the cycles at the 1.6 GHz the
+// power management leaves under this load (tools/ubench/mfma_bf16_peak.hip).  A launch can hold several
+// independent products (grid y: split-K slabs) and a product can run over a k range of larger planes (plane strides).
 #include "skm_gemm.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
